@@ -1,0 +1,228 @@
+/*
+ * mgs.h — C ABI of libmgs.so: the MI355X (gfx950) solve-phase hot path of an
+ * aggregation-based AMG V-cycle behind the surface of mishraiiit/MultiGridSolver.
+ *
+ * The reference has no FFI boundary (one translation unit per
+ * program); the surface it exposes is source level.  Every entry point below names the
+ * reference interface (file:line, relative to the reference checkout) it replaces or
+ * serves.  The C++ face that keeps the reference's spelling (readMatrix, SMatrix,
+ * MultiGridPrecond(A,P).solve(v), BiCGSTABiml) is multigridsolver_amd/cpp/mgs_host.hpp,
+ * written on top of this header only.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; opaque handles; every call returns int
+ *     (MGS_OK = 0, negative = error class) and records a message retrievable with
+ *     mgs_last_error().
+ *   - matrices: CSR, f64 values, int32 indices, columns sorted inside a row — the layout
+ *     of `typedef SparseMatrix<double,RowMajor> SMatrix` (src/common/MatrixIO.cpp:10).
+ *   - host arrays are caller-owned and copied on upload; device memory is owned by the
+ *     library and released by the matching *_destroy.
+ *   - one context = one HIP device + one stream; calls are asynchronous on that stream
+ *     unless they return a host scalar or copy to host memory.  A context is not
+ *     thread-safe.
+ *   - there is NO CPU fallback: every compute entry point runs HIP kernels on the
+ *     context's device and fails with MGS_ERR_HIP if that is impossible.
+ */
+#ifndef MGS_H
+#define MGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_OK 0
+#define MGS_ERR_INVALID (-1) /* bad argument / shape mismatch                        */
+#define MGS_ERR_HIP (-2)     /* HIP runtime failure (no device, launch error, ...)   */
+#define MGS_ERR_IO (-3)      /* file open / parse failure                            */
+#define MGS_ERR_ALLOC (-4)   /* host or device allocation failed                     */
+#define MGS_ERR_NUMERIC (-5) /* zero diagonal, singular coarse operator, ...         */
+#define MGS_ERR_STATE (-6)   /* call sequence error (e.g. V-cycle before finalize)   */
+
+typedef struct mgs_ctx mgs_ctx;
+typedef struct mgs_csr mgs_csr;   /* device CSR matrix                               */
+typedef struct mgs_vec mgs_vec;   /* device f64 vector                               */
+typedef struct mgs_xfer mgs_xfer; /* prolongation P with its restriction Pᵀ          */
+typedef struct mgs_hier mgs_hier; /* multilevel hierarchy = the preconditioner state */
+
+/* ------------------------------------------------------------------ context */
+/* device: HIP device ordinal.  stream: a hipStream_t to launch on (e.g. the caller's
+ * torch stream) or NULL to let the context create its own.                          */
+int mgs_ctx_create(int device, void *stream, mgs_ctx **out);
+int mgs_ctx_destroy(mgs_ctx *ctx);
+const char *mgs_last_error(const mgs_ctx *ctx); /* ctx may be NULL: last global error */
+int mgs_sync(mgs_ctx *ctx);                      /* hipStreamSynchronize              */
+void *mgs_ctx_stream(mgs_ctx *ctx);              /* the hipStream_t in use            */
+const char *mgs_version(void);
+
+/* ------------------------------------------------ L0 I/O: Matrix-Market loader (host) */
+/* readMatrix  — src/common/MatrixIO.cpp:12-37 (twin: src/GPU_CUDAC++/MatrixIO.cu:182-280):
+ * leading '%' lines skipped, "M N L", L triples "i j v" 1-based in any order, bucketed by
+ * row, each row sorted by column; coordinate real general only.  Output arrays are
+ * malloc'ed by the library; release each with mgs_host_free.  Unlike the reference a
+ * missing/short file is an error (MGS_ERR_IO) instead of undefined behaviour.          */
+int mgs_mtx_read(const char *path, int *rows, int *cols, int *nnz,
+                 int **rowptr, int **col, double **val);
+/* writeMatrix — src/common/MatrixIO.cpp:39-57: banner "%%MatrixMarket matrix coordinate
+ * real general " + "rows cols nnz" + row-major 1-based triples, default ostream precision
+ * (6 significant digits).                                                             */
+int mgs_mtx_write(const char *path, int rows, int cols, int nnz,
+                  const int *rowptr, const int *col, const double *val);
+void mgs_host_free(void *p);
+
+/* ------------------------------------------------------------ device CSR (row a1/a10) */
+/* Replaces deepCopyMatrixCSRCPUtoGPU / deepCopyMatrixCSRGPUtoCPU
+ * (src/GPU_CUDAC++/MatrixOperations.cu:121-146,162-171): sizes stay on the host, raw
+ * device arrays inside.  nnz is int64 in the signatures for headroom; indices are int32
+ * so nnz must be < 2^31.                                                              */
+int mgs_csr_upload(mgs_ctx *ctx, int rows, int cols, int64_t nnz, const int *rowptr,
+                   const int *col, const double *val, mgs_csr **out);
+int mgs_csr_download(const mgs_csr *A, int *rowptr, int *col, double *val);
+int mgs_csr_shape(const mgs_csr *A, int *rows, int *cols, int64_t *nnz);
+int mgs_csr_destroy(mgs_csr *A);
+/* device pointers (for zero-copy interop, e.g. the Eigen CPU baseline after download) */
+int mgs_csr_device_ptrs(const mgs_csr *A, void **rowptr, void **col, void **val);
+/* Synthetic operator generated on device: 7-point 3-D Poisson on an
+ * N^3 grid, 3-D extension of src/common/poisson.cpp:11-33 (diag 6, off-diagonals −1,
+ * row e=(i*N+j)*N+k, ascending columns).  Rows of planes [plane_lo, plane_hi) only
+ * (row-range shard); columns are global unless local_cols != 0, in which case they are
+ * renumbered to [0,n_loc) for owned and n_loc.. for the lower/upper halo planes.       */
+int mgs_csr_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols,
+                      mgs_csr **out);
+/* Same stencil family in 2-D exactly as src/common/poisson.cpp:9-37 (n^2 rows, 4/−1).  */
+int mgs_csr_poisson2d(mgs_ctx *ctx, int n, mgs_csr **out);
+/* Bᵀ materialised row-major (bicg.cpp:32 `Ptrans = P.transpose()`).                    */
+int mgs_csr_transpose(const mgs_csr *A, mgs_csr **out);
+/* A_c = PᵀAP (bicg.cpp:33).  Runs on device.                                          */
+int mgs_csr_galerkin(const mgs_csr *A, const mgs_xfer *P, mgs_csr **out);
+
+/* -------------------------------------------------------------------- device vectors */
+/* Eigen::VectorXd on the device (bicg.cpp:153-162).                                    */
+int mgs_vec_create(mgs_ctx *ctx, int64_t n, mgs_vec **out);
+/* non-owning view of caller device memory (e.g. a torch tensor's data_ptr)            */
+int mgs_vec_wrap(mgs_ctx *ctx, void *device_ptr, int64_t n, mgs_vec **out);
+int mgs_vec_destroy(mgs_vec *v);
+int mgs_vec_upload(mgs_vec *v, const double *host, int64_t n);
+int mgs_vec_download(const mgs_vec *v, double *host, int64_t n);
+int mgs_vec_fill(mgs_vec *v, double value);
+int mgs_vec_copy(const mgs_vec *src, mgs_vec *dst);
+int64_t mgs_vec_size(const mgs_vec *v);
+void *mgs_vec_ptr(const mgs_vec *v);
+/* counter-based uniform [0,1): splitmix64(seed, global_index)      */
+int mgs_vec_rand(mgs_vec *v, uint64_t seed, int64_t global_offset);
+
+/* ------------------------------------------------------ L1 hot-path primitives (★)   */
+/* y = A x — `A * v`, bicg.cpp:57,82,107,117; Eigen kernel
+ * lib/Eigen/src/SparseCore/SparseDenseProduct.h:26-71.                                */
+int mgs_spmv(const mgs_csr *A, const mgs_vec *x, mgs_vec *y);
+/* r = b − A x — bicg.cpp:82.                                                          */
+int mgs_residual(const mgs_csr *A, const mgs_vec *x, const mgs_vec *b, mgs_vec *r);
+/* dinv_i = 1/a_ii — M2 = diag(diag(A))\x, src/CPU_Matlab/solve.m:17.  Fails with
+ * MGS_ERR_NUMERIC if a diagonal entry is missing or zero.                             */
+int mgs_diag_inv(const mgs_csr *A, mgs_vec *dinv);
+/* x_out = x_in + ω D⁻¹ (b − A x_in), out of place (x_out must not alias x_in) —
+ * SURVEY §8a row a7; spec solve.m:17 + paper eq. (3.5).                               */
+int mgs_jacobi(const mgs_csr *A, const mgs_vec *dinv, double omega, const mgs_vec *b,
+               const mgs_vec *x_in, mgs_vec *x_out);
+
+/* Prolongation operator.  P is taken as CSR (what readMatrix returns for
+ * <name>promatrix_<tag>.mtx, bicg.cpp:151).  If every row holds at most one entry of
+ * value exactly 1 (how AGMG builds it: src/CPU_C++/AGMG.cpp:181-186,
+ * src/GPU_CUDAC++/Aggregation.cu:252-270) the aggregate-id form is used; any other P
+ * runs through the general CSR kernels with Pᵀ materialised (bicg.cpp:32).            */
+int mgs_xfer_create(const mgs_csr *P, mgs_xfer **out);
+int mgs_xfer_destroy(mgs_xfer *T);
+int mgs_xfer_shape(const mgs_xfer *T, int *n_fine, int *n_coarse, int *is_aggregation);
+/* r_c = Pᵀ r — `Ptrans * vec`, bicg.cpp:48.                                           */
+int mgs_restrict(const mgs_xfer *T, const mgs_vec *r, mgs_vec *rc);
+/* e = P e_c — `P * (...)`, bicg.cpp:48.                                               */
+int mgs_prolong(const mgs_xfer *T, const mgs_vec *ec, mgs_vec *e);
+/* x += P e_c (the coarse-grid correction of the V-cycle).                             */
+int mgs_prolong_add(const mgs_xfer *T, const mgs_vec *ec, mgs_vec *x);
+
+/* BLAS-1 used by BiCGSTABiml (bicg.cpp:64-72,95,101-120): free dot()/norm() and the
+ * vector updates.  dot/nrm2 synchronise and return a host scalar.                     */
+int mgs_dot(const mgs_vec *x, const mgs_vec *y, double *out);
+int mgs_nrm2(const mgs_vec *x, double *out);
+int mgs_axpby(double a, const mgs_vec *x, double b, mgs_vec *y); /* y = a x + b y      */
+int mgs_axpbypcz(double a, const mgs_vec *x, double b, const mgs_vec *y, double c,
+                 mgs_vec *z);                                    /* z = a x + b y + c z */
+
+/* ------------------------------------------- L3 preconditioner: multilevel V-cycle (★) */
+/* MultiGridPrecond(A, P) — bicg.cpp:19-62.  A is borrowed (must outlive the hierarchy).
+ * Level l cycle: ν1 damped-Jacobi sweeps, r = b − Ax, r_c = Pᵀr, recurse from 0,
+ * x += P e_c, ν2 sweeps; coarsest level solved directly (dense inverse built on device,
+ * stands in for SparseLU, bicg.cpp:35-36).  Two-level with ν1=0, ν2=1 is bicg.cpp:46-61
+ * with M2 = ωD⁻¹.                                                                     */
+int mgs_hier_create(mgs_ctx *ctx, const mgs_csr *A, double omega, int nu1, int nu2,
+                    mgs_hier **out);
+/* append a level from a given prolongation (P.rows == rows of current coarsest);
+ * computes A_c = PᵀAP on device (bicg.cpp:32-33).                                     */
+int mgs_hier_push_P(mgs_hier *h, const mgs_csr *P);
+/* append levels by on-device pairwise aggregation (Notay AGMG: src/CPU_C++/AGMG.cpp:
+ * 299-315, src/GPU_CUDAC++/main.cu:95-277) until the coarsest has <= coarse_rows rows,
+ * max_levels is reached or coarsening stalls.  ktg/npass/tou as the reference's argv
+ * (src/CPU_C++/main.cpp:155-182; benchmarks use 10 2 8, results.txt:22-24).           */
+int mgs_hier_coarsen(mgs_hier *h, double ktg, int npass, double tou, int coarse_rows,
+                     int max_levels);
+/* factor the coarsest operator; must be called once before mgs_vcycle.                */
+int mgs_hier_finalize(mgs_hier *h);
+int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
+int mgs_hier_destroy(mgs_hier *h);
+int mgs_hier_nlev(const mgs_hier *h);
+int mgs_hier_level_shape(const mgs_hier *h, int level, int *rows, int64_t *nnz);
+/* borrowed handles of level operators / transfer (valid while h lives)                */
+const mgs_csr *mgs_hier_level_A(const mgs_hier *h, int level);
+const mgs_xfer *mgs_hier_level_P(const mgs_hier *h, int level);
+/* aggregate id of every fine row of `level` (−1 = not aggregated, G0) to host         */
+int mgs_xfer_download_agg(const mgs_xfer *T, int *agg);
+/* algorithmic HBM bytes of one V-cycle application (DESIGN.md §5 formula)             */
+int64_t mgs_hier_vcycle_bytes(const mgs_hier *h);
+
+/* One V-cycle: x ← cycle(b) from x=0 if zero_guess else improving the x passed in.
+ * MultiGridPrecond::solve (bicg.cpp:51-61) == mgs_vcycle(h, v, out, 1).              */
+int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess);
+
+/* ------------------------------------------------------ L4 Krylov: BiCGSTABiml (f-2) */
+/* bicg.cpp:74-136, device resident.  h may be NULL (identity preconditioner).  On
+ * return *max_iter = iterations done, *tol = achieved relative residual; the int result
+ * of the reference (0 ok / 1 max_iter / 2 rho breakdown / 3 omega breakdown) is written
+ * to *status; the function's own return value is the MGS_* error class.               */
+int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h,
+                 int *max_iter, double *tol, int *status);
+
+/* ------------------------------------------------------------- multi-GPU row shards   */
+/* Halo plan of a row-range shard whose CSR uses LOCAL column numbering: columns
+ * [0,n_loc) are owned rows, columns n_loc+k are halo slot k.  send_idx lists the owned
+ * rows this rank must pack for its peers (concatenated in peer order).  The pack kernel
+ * gathers x[send_idx] into send_buf; the exchange itself is done by the caller (RCCL via
+ * torch.distributed) between mgs_halo_pack and the next kernel that reads x's halo.   */
+int mgs_halo_pack(mgs_ctx *ctx, const mgs_vec *x, const int *send_idx_dev, int64_t n_send,
+                  double *send_buf_dev);
+/* exchange callback installed on a hierarchy: called with (user, level, x_dev) before
+ * every kernel that gathers off-shard entries of x on that level; x_dev has n_loc +
+ * n_halo entries and the callee must fill x_dev[n_loc..] on ctx's stream.             */
+typedef int (*mgs_halo_fn)(void *user, int level, void *x_dev);
+int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user);
+/* reduction callback for dot products of sharded vectors (sum over ranks)             */
+typedef int (*mgs_allreduce_fn)(void *user, double *host_scalars, int count);
+int mgs_ctx_set_allreduce(mgs_ctx *ctx, mgs_allreduce_fn fn, void *user);
+
+/* ------------------------------------------------------------------ instrumentation  */
+/* Time `reps` back-to-back launches of one hot-path kernel with hipEvents on the
+ * context's stream (what bench.py's roofline.achieved uses).  op: 0 spmv, 1 residual,
+ * 2 jacobi.  Returns mean milliseconds per launch in *ms.                              */
+int mgs_time_kernel(const mgs_csr *A, int op, const mgs_vec *x, const mgs_vec *b,
+                    const mgs_vec *dinv, mgs_vec *out, int reps, double *ms);
+/* Time `reps` V-cycles with hipEvents on the context's stream.                        */
+int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double *ms);
+/* kernel-variant knobs for A/B measurements (0 = default).  key: "spmv_variant",
+ * "xcd_remap", "nontemporal", "graph".                                                */
+int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGS_H */

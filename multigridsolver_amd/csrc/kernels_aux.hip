@@ -1,0 +1,414 @@
+// kernels_aux.hip — grid transfer (restriction / prolongation), BLAS-1, coarsest dense solve,
+// on-device operator generators, halo pack.  gfx950 only.
+#include "mgs_internal.hpp"
+
+namespace {
+constexpr int TB = 256;
+
+// ------------------------------------------------------------------ diag / elementwise
+// dinv_i = 1/a_ii (reference src/CPU_Matlab/solve.m:17).  Binary search in the sorted row,
+// as src/GPU_CUDAC++/MatrixAccess.cu:28-47 does for element access.
+__global__ void diag_inv_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                const double *__restrict__ val, double *__restrict__ dinv, int *__restrict__ bad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = rowptr[i], hi = rowptr[i + 1] - 1;
+  double d = 0.0;
+  while (lo <= hi) {
+    int mid = (lo + hi) >> 1;
+    int c = col[mid];
+    if (c == i) { d = val[mid]; break; }
+    if (c < i) lo = mid + 1; else hi = mid - 1;
+  }
+  if (d == 0.0) { atomicAdd(bad, 1); dinv[i] = 0.0; }
+  else dinv[i] = 1.0 / d;
+}
+
+__global__ void fill_kernel(double *__restrict__ d, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = v;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void rand_kernel(double *__restrict__ d, int64_t n, uint64_t seed, int64_t off) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t h = splitmix64(seed * 0xD1342543DE82EF95ull + (uint64_t)(i + off));
+    d[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+  }
+}
+
+__global__ void axpby_kernel(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (b == 0.0) { for (; i < n; i += stride) y[i] = a * x[i]; }
+  else { for (; i < n; i += stride) y[i] = a * x[i] + b * y[i]; }
+}
+__global__ void axpbypcz_kernel(int64_t n, double a, const double *__restrict__ x, double b,
+                                const double *__restrict__ y, double c, double *__restrict__ z) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (c == 0.0) { for (; i < n; i += stride) z[i] = a * x[i] + b * y[i]; }
+  else { for (; i < n; i += stride) z[i] = a * x[i] + b * y[i] + c * z[i]; }
+}
+
+// first damped-Jacobi sweep from x = 0: x = 0 + (ωD⁻¹)(b − A·0) = (ω·dinv_i)·b_i, bit-identical
+__global__ void jacobi_zero_kernel(int n, double omega, const double *__restrict__ dinv, const double *__restrict__ b, double *__restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (omega * dinv[i]) * b[i];
+}
+
+// ------------------------------------------------------------------ grid transfer
+// r_c = Pᵀ r for an aggregation P (unit values are not loaded): `Ptrans * vec`,
+// reference bicg.cpp:48.  One lane per aggregate, members summed in ascending fine-row
+// order == Eigen's row-major SpMV order with values 1.0 → bit-identical.
+__global__ void restrict_agg_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members,
+                                    const double *__restrict__ r, double *__restrict__ rc) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  double s = 0.0;
+  for (int k = cptr[c], e = cptr[c + 1]; k < e; ++k) s += r[members[k]];
+  rc[c] = s;
+}
+// e = P e_c / x += P e_c: `P * (...)`, reference bicg.cpp:48; P has ≤1 unit entry per row
+// (src/CPU_C++/AGMG.cpp:181-186) so e_i = e_c[agg(i)] or 0 for G0 rows.
+template <int ADD>
+__global__ void prolong_agg_kernel(int n, const int *__restrict__ agg, const double *__restrict__ ec, double *__restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int a = agg[i];
+  double e = a >= 0 ? ec[a] : 0.0;
+  if (ADD) x[i] += e; else x[i] = e;
+}
+
+__global__ void gather_kernel(const double *__restrict__ x, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[idx[i]];
+}
+
+// ------------------------------------------------------------------ reductions
+// Two-stage deterministic dot: fixed grid of partials (independent of scheduling), then one
+// block folds them in index order.  reference bicg.cpp:64-72 (dot/norm helpers).
+constexpr int DOT_BLOCKS = 1024;
+__global__ __launch_bounds__(TB) void dot_partial_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part) {
+  __shared__ double sh[TB / 64];
+  double s = 0.0;
+  int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * TB;
+  for (; i < n; i += stride) s += x[i] * y[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < TB / 64; ++w) t += sh[w]; part[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(TB) void dot_final_kernel(int nb, const double *__restrict__ part, double *__restrict__ out) {
+  __shared__ double sh[TB];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += TB) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = TB / 2; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ------------------------------------------------------------------ coarsest level: dense
+// x = A⁻¹ b with the explicit inverse (stands in for SparseLU::solve, reference bicg.cpp:48).
+// One wavefront per row, lanes stride the columns (coalesced), shuffle reduction.
+__global__ __launch_bounds__(TB) void dense_gemv_kernel(int n, const double *__restrict__ M, const double *__restrict__ b, double *__restrict__ x) {
+  int row = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const double *m = M + (size_t)row * n;
+  double s = 0.0;
+  for (int j = lane; j < n; j += 64) s += m[j] * b[j];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) x[row] = s;
+}
+
+// Gauss-Jordan inversion with partial pivoting on the augmented matrix [A | I] (n × 2n).
+__global__ void dense_scatter_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, double *__restrict__ W) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double *w = W + (size_t)i * 2 * n;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) w[col[k]] += val[k];
+  w[n + i] = 1.0;
+}
+__global__ __launch_bounds__(TB) void gj_pivot_kernel(int n, int k, const double *__restrict__ W, int *__restrict__ piv, double *__restrict__ pivval) {
+  __shared__ double bv[TB]; __shared__ int bi[TB];
+  double best = -1.0; int idx = k;
+  for (int i = k + threadIdx.x; i < n; i += TB) {
+    double v = fabs(W[(size_t)i * 2 * n + k]);
+    if (v > best) { best = v; idx = i; }
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int w = TB / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) {
+      double o = bv[threadIdx.x + w]; int oi = bi[threadIdx.x + w];
+      if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { piv[0] = bi[0]; if (bv[0] == 0.0) piv[1] = 1; pivval[0] = W[(size_t)bi[0] * 2 * n + k]; }
+}
+__global__ void gj_swap_scale_kernel(int n, int k, double *__restrict__ W, const int *__restrict__ piv, const double *__restrict__ pivval) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = piv[0];
+  if (j < 2 * n) {
+    double a = W[(size_t)k * 2 * n + j], b = W[(size_t)p * 2 * n + j];
+    double d = pivval[0];
+    if (d == 0.0) d = 1.0;
+    W[(size_t)p * 2 * n + j] = a;       // (p == k: a == b, harmless)
+    W[(size_t)k * 2 * n + j] = b / d;
+  }
+}
+__global__ void gj_colsave_kernel(int n, int k, const double *__restrict__ W, double *__restrict__ colk) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) colk[i] = (i == k) ? 0.0 : W[(size_t)i * 2 * n + k];
+}
+__global__ void gj_eliminate_kernel(int n, int k, double *__restrict__ W, const double *__restrict__ colk) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (j >= 2 * n) return;
+  double f = colk[i];
+  if (f != 0.0) W[(size_t)i * 2 * n + j] -= f * W[(size_t)k * 2 * n + j];
+}
+__global__ void gj_extract_kernel(int n, const double *__restrict__ W, double *__restrict__ inv) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (j < n) inv[(size_t)i * n + j] = W[(size_t)i * 2 * n + n + j];
+}
+
+// ------------------------------------------------------------------ generators
+// 7-point 3-D Poisson, SURVEY §8d row d2 (3-D extension of reference src/common/poisson.cpp:11-33).
+// closed-form rowptr: entries before row e = 7e − (#missing neighbours in rows < e)
+__device__ __forceinline__ int64_t p3_rowptr(int N, int64_t e) {
+  const int64_t N2 = (int64_t)N * N;
+  if (e >= N2 * N) return 7 * N2 * N - 6 * N2;
+  int i = (int)(e / N2); int rem = (int)(e - (int64_t)i * N2); int j = rem / N; int k = rem - j * N;
+  // missing i−: rows with i==0 before e; missing i+: rows with i==N-1 before e
+  int64_t miss = 0;
+  miss += (i > 0) ? N2 : rem;                     // i == 0 rows
+  miss += (i == N - 1) ? rem : 0;                 // i == N-1 rows
+  // j == 0 rows before e: per full plane N, in current plane: (j>0 ? N : k)
+  miss += (int64_t)i * N + ((j > 0) ? N : k);
+  miss += (int64_t)i * N + ((j == N - 1) ? k : 0);   // j == N-1 rows
+  // k == 0 rows before e: one per line
+  int64_t lines = (int64_t)i * N + j;
+  miss += lines + (k > 0 ? 1 : 0);
+  miss += lines;                                      // k == N-1 rows of complete lines
+  return 7 * e - miss;
+}
+__global__ void poisson3d_kernel(int N, int plane_lo, int64_t n_loc, int local_cols, int has_lo, int has_hi,
+                                 int *__restrict__ rowptr, int *__restrict__ col, double *__restrict__ val) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_loc) return;
+  const int64_t N2 = (int64_t)N * N;
+  const int64_t e0 = (int64_t)plane_lo * N2;
+  const int64_t base = p3_rowptr(N, e0);
+  const int64_t e = e0 + t;
+  const int64_t p0 = p3_rowptr(N, e) - base;
+  rowptr[t] = (int)p0;
+  if (t == n_loc) return;
+  int i = (int)(e / N2); int rem = (int)(e - (int64_t)i * N2); int j = rem / N; int k = rem - j * N;
+  int64_t p = p0;
+  // local numbering: owned rows [0,n_loc), lower halo plane [n_loc, n_loc+N2), upper after it
+  const int64_t lo_halo = n_loc, hi_halo = n_loc + (has_lo ? N2 : 0);
+  auto cidx = [&](int64_t g) -> int {
+    if (!local_cols) return (int)g;
+    int64_t l = g - e0;
+    if (l < 0) return (int)(lo_halo + (l + N2));
+    if (l >= n_loc) return (int)(hi_halo + (l - n_loc));
+    return (int)l;
+  };
+  if (i > 0)     { col[p] = cidx(e - N2); val[p++] = -1.0; }
+  if (j > 0)     { col[p] = cidx(e - N);  val[p++] = -1.0; }
+  if (k > 0)     { col[p] = cidx(e - 1);  val[p++] = -1.0; }
+  col[p] = cidx(e); val[p++] = 6.0;
+  if (k < N - 1) { col[p] = cidx(e + 1);  val[p++] = -1.0; }
+  if (j < N - 1) { col[p] = cidx(e + N);  val[p++] = -1.0; }
+  if (i < N - 1) { col[p] = cidx(e + N2); val[p++] = -1.0; }
+}
+// 2-D 5-point, exactly reference src/common/poisson.cpp:9-37.
+__global__ void poisson2d_kernel(int n, int *__restrict__ rowptr, int *__restrict__ col, double *__restrict__ val) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int N = n * n;
+  if (e > N) return;
+  auto rp = [&](int r) -> int {
+    if (r >= N) return 5 * N - 4 * n;
+    int i = r / n, j = r % n;
+    // missing: i==0 rows, i==n-1 rows, j==0 rows, j==n-1 rows before r
+    int miss = (i > 0 ? n : j) + (i == n - 1 ? j : 0) + (i + (j > 0 ? 1 : 0)) + i;
+    return 5 * r - miss;
+  };
+  int p = rp(e);
+  rowptr[e] = p;
+  if (e == N) return;
+  int i = e / n, j = e % n;
+  if (i > 0)     { col[p] = e - n; val[p++] = -1.0; }
+  if (j > 0)     { col[p] = e - 1; val[p++] = -1.0; }
+  col[p] = e; val[p++] = 4.0;
+  if (j < n - 1) { col[p] = e + 1; val[p++] = -1.0; }
+  if (i < n - 1) { col[p] = e + n; val[p++] = -1.0; }
+}
+
+}  // namespace
+
+// ============================================================ host launchers
+static inline int grid_cap(int64_t n, int ncu) {
+  int64_t g = (n + TB - 1) / TB;
+  int64_t cap = (int64_t)ncu * 8;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host) {
+  mgs_ctx *ctx = A->ctx;
+  int *bad = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &bad, 1));
+  MGS_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+  if (A->rows)
+    hipLaunchKernelGGL(diag_inv_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, A->val, dinv, bad);
+  MGS_HIP(ctx, hipMemcpyAsync(bad_count_host, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MGS_HIP(ctx, hipFree(bad));
+  return MGS_OK;
+}
+
+int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc) {
+  if (nc) hipLaunchKernelGGL(restrict_agg_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, r, rc);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_prolong_agg(mgs_ctx *ctx, int n, const int *agg, const double *ec, double *x, int add) {
+  if (n) {
+    if (add) hipLaunchKernelGGL(prolong_agg_kernel<1>, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, agg, ec, x);
+    else hipLaunchKernelGGL(prolong_agg_kernel<0>, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, agg, ec, x);
+  }
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const double *b, double *x) {
+  if (n) hipLaunchKernelGGL(jacobi_zero_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, omega, dinv, b, x);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_fill(mgs_ctx *ctx, double *d, int64_t n, double v) {
+  if (n) hipLaunchKernelGGL(fill_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, d, n, v);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off) {
+  if (n) hipLaunchKernelGGL(rand_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, d, n, seed, off);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
+  if (n) hipLaunchKernelGGL(axpby_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z) {
+  if (n) hipLaunchKernelGGL(axpbypcz_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_gather(mgs_ctx *ctx, const double *x, const int *idx, int64_t n, double *out) {
+  if (n) hipLaunchKernelGGL(gather_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, x, idx, n, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+
+int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host) {
+  int nb = (int)((n + TB - 1) / TB);
+  if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out_host = ctx->red_host[0];
+  if (ctx->allreduce) {
+    int rc = ctx->allreduce(ctx->allreduce_user, out_host, 1);
+    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
+  }
+  return MGS_OK;
+}
+
+int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *x) {
+  if (n) hipLaunchKernelGGL(dense_gemv_kernel, dim3(mgs_grid(n, TB / 64)), dim3(TB), 0, ctx->stream, n, M, b, x);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+
+int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out) {
+  const int n = A->rows;
+  MGS_CHECK(ctx, A->cols == n, MGS_ERR_INVALID, "coarsest operator is not square (%d x %d)", A->rows, A->cols);
+  double *W = nullptr, *colk = nullptr, *inv = nullptr; int *piv = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &W, (size_t)n * 2 * n));
+  MGS_TRY(mgs_dev_alloc(ctx, &colk, (size_t)n + 1));
+  MGS_TRY(mgs_dev_alloc(ctx, &inv, (size_t)n * n));
+  MGS_TRY(mgs_dev_alloc(ctx, &piv, 2));
+  hipStream_t s = ctx->stream;
+  MGS_HIP(ctx, hipMemsetAsync(W, 0, sizeof(double) * (size_t)n * 2 * n, s));
+  MGS_HIP(ctx, hipMemsetAsync(piv, 0, 2 * sizeof(int), s));
+  if (n) hipLaunchKernelGGL(dense_scatter_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, s, n, A->rowptr, A->col, A->val, W);
+  for (int k = 0; k < n; ++k) {
+    hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(TB), 0, s, n, k, W, piv, colk + n);
+    hipLaunchKernelGGL(gj_swap_scale_kernel, dim3(mgs_grid(2 * n, TB)), dim3(TB), 0, s, n, k, W, piv, colk + n);
+    hipLaunchKernelGGL(gj_colsave_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, s, n, k, W, colk);
+    hipLaunchKernelGGL(gj_eliminate_kernel, dim3(mgs_grid(2 * n, TB), n), dim3(TB), 0, s, n, k, W, colk);
+  }
+  if (n) hipLaunchKernelGGL(gj_extract_kernel, dim3(mgs_grid(n, TB), n), dim3(TB), 0, s, n, W, inv);
+  int h[2] = {0, 0};
+  MGS_HIP(ctx, hipMemcpyAsync(h, piv, sizeof h, hipMemcpyDeviceToHost, s));
+  MGS_HIP(ctx, hipStreamSynchronize(s));
+  MGS_HIP(ctx, hipFree(W)); MGS_HIP(ctx, hipFree(colk)); MGS_HIP(ctx, hipFree(piv));
+  if (h[1]) { hipFree(inv); return mgs_fail(ctx, MGS_ERR_NUMERIC, "coarsest operator (%d rows) is singular", n); }
+  *inv_out = inv;
+  return MGS_OK;
+}
+
+int k_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out) {
+  MGS_CHECK(ctx, N >= 2 && plane_lo >= 0 && plane_hi <= N && plane_lo < plane_hi, MGS_ERR_INVALID, "poisson3d: bad N/planes");
+  const int64_t N2 = (int64_t)N * N, n_loc = (int64_t)(plane_hi - plane_lo) * N2;
+  // nnz of the shard = rowptr(e1) − rowptr(e0); computed on host with the same closed form
+  auto rp = [&](int64_t e) -> int64_t {
+    if (e >= N2 * N) return 7 * N2 * N - 6 * N2;
+    int64_t i = e / N2;  // e is a plane boundary here
+    // rows before plane i: 7 per row minus missing neighbours
+    int64_t rows = i * N2;
+    int64_t miss = (i > 0 ? N2 : 0) + 0 /*i==N-1 rows before: none unless i==N*/ + 2 * i * N /*j==0,N-1*/ + 2 * i * N /*k==0,N-1*/;
+    return 7 * rows - miss;
+  };
+  const int64_t nnz = rp((int64_t)plane_hi * N2) - rp((int64_t)plane_lo * N2);
+  MGS_CHECK(ctx, nnz < 2147483647LL && n_loc < 2147483647LL, MGS_ERR_INVALID, "poisson3d shard too large for int32 indices");
+  const int has_lo = plane_lo > 0, has_hi = plane_hi < N;
+  int64_t ncols = local_cols ? n_loc + (has_lo + has_hi) * N2 : N2 * N;
+  MGS_CHECK(ctx, ncols < 2147483647LL, MGS_ERR_INVALID, "poisson3d: too many columns for int32");
+  mgs_csr *A = nullptr;
+  MGS_TRY(mgs_csr_alloc(ctx, (int)n_loc, (int)ncols, nnz, &A));
+  hipLaunchKernelGGL(poisson3d_kernel, dim3(mgs_grid(n_loc + 1, TB)), dim3(TB), 0, ctx->stream, N, plane_lo, n_loc, local_cols, has_lo, has_hi, A->rowptr, A->col, A->val);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_TRY(mgs_plan_csr(A));
+  *out = A;
+  return MGS_OK;
+}
+
+int k_poisson2d(mgs_ctx *ctx, int n, mgs_csr **out) {
+  MGS_CHECK(ctx, n >= 2 && (int64_t)n * n < 400000000LL, MGS_ERR_INVALID, "poisson2d: bad n");
+  int N = n * n; int64_t nnz = 5LL * N - 4LL * n;
+  mgs_csr *A = nullptr;
+  MGS_TRY(mgs_csr_alloc(ctx, N, N, nnz, &A));
+  hipLaunchKernelGGL(poisson2d_kernel, dim3(mgs_grid(N + 1, TB)), dim3(TB), 0, ctx->stream, n, A->rowptr, A->col, A->val);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_TRY(mgs_plan_csr(A));
+  *out = A;
+  return MGS_OK;
+}

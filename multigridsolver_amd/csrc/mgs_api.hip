@@ -1,0 +1,579 @@
+// mgs_api.hip — C-ABI implementation (include/mgs.h): context, device containers, the
+// multilevel hierarchy and the host-side V-cycle / BiCGSTAB orchestration.  The host logic
+// is C++; every numeric step is a HIP kernel on the context's stream.  No CPU fallback.
+#include "mgs_internal.hpp"
+
+#include <cmath>
+
+thread_local std::string g_mgs_last_error;
+
+int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_mgs_last_error = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+extern "C" {
+
+const char *mgs_version(void) { return "multigridsolver_amd 0.1 (gfx950, f64)"; }
+
+// ------------------------------------------------------------------ context
+int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
+  if (!out) return mgs_fail(nullptr, MGS_ERR_INVALID, "mgs_ctx_create: out is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return mgs_fail(nullptr, MGS_ERR_HIP, "no HIP device available (%s): libmgs has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return mgs_fail(nullptr, MGS_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+  MGS_HIP(nullptr, hipSetDevice(device));
+  mgs_ctx *c = new mgs_ctx();
+  c->device = device;
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return mgs_fail(nullptr, MGS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  c->red_cap = 2048;
+  if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16) != hipSuccess) {
+    delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
+  }
+  *out = c;
+  return MGS_OK;
+}
+int mgs_ctx_destroy(mgs_ctx *c) {
+  if (!c) return MGS_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->red_dev) hipFree(c->red_dev);
+  if (c->red_host) hipHostFree(c->red_host);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return MGS_OK;
+}
+const char *mgs_last_error(const mgs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_mgs_last_error.c_str(); }
+int mgs_sync(mgs_ctx *ctx) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MGS_OK; }
+void *mgs_ctx_stream(mgs_ctx *ctx) { return (void *)ctx->stream; }
+int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
+  std::string k(key ? key : "");
+  if (k == "xcd_remap") ctx->opt_xcd_remap = value;
+  else if (k == "nontemporal") ctx->opt_nontemporal = value;
+  else if (k == "spmv_variant") ctx->opt_spmv_variant = value;
+  else if (k == "graph") ctx->opt_graph = value;
+  else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
+  return MGS_OK;
+}
+int mgs_ctx_set_allreduce(mgs_ctx *ctx, mgs_allreduce_fn fn, void *user) { ctx->allreduce = fn; ctx->allreduce_user = user; return MGS_OK; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ CSR
+int mgs_csr_alloc(mgs_ctx *ctx, int rows, int cols, int64_t nnz, mgs_csr **out) {
+  MGS_CHECK(ctx, rows >= 0 && cols >= 0 && nnz >= 0 && nnz < 2147483647LL, MGS_ERR_INVALID, "csr: bad shape %d x %d nnz %lld", rows, cols, (long long)nnz);
+  mgs_csr *A = new mgs_csr();
+  A->ctx = ctx; A->rows = rows; A->cols = cols; A->nnz = nnz;
+  int rc = mgs_dev_alloc(ctx, &A->rowptr, (size_t)rows + 1);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &A->col, (size_t)nnz + 4);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &A->val, (size_t)nnz + 4);
+  if (rc != MGS_OK) { mgs_csr_destroy(A); return rc; }
+  *out = A;
+  return MGS_OK;
+}
+
+extern "C" {
+
+int mgs_csr_upload(mgs_ctx *ctx, int rows, int cols, int64_t nnz, const int *rowptr, const int *col, const double *val, mgs_csr **out) {
+  MGS_CHECK(ctx, ctx && out && rowptr && (nnz == 0 || (col && val)), MGS_ERR_INVALID, "mgs_csr_upload: NULL argument");
+  MGS_CHECK(ctx, rowptr[0] == 0 && rowptr[rows] == nnz, MGS_ERR_INVALID, "mgs_csr_upload: rowptr[0]=%d rowptr[rows]=%d nnz=%lld inconsistent", rowptr[0], rowptr[rows], (long long)nnz);
+  for (int i = 0; i < rows; ++i) {
+    MGS_CHECK(ctx, rowptr[i] <= rowptr[i + 1], MGS_ERR_INVALID, "mgs_csr_upload: rowptr not monotone at row %d", i);
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      MGS_CHECK(ctx, col[k] >= 0 && col[k] < cols, MGS_ERR_INVALID, "mgs_csr_upload: column %d out of range in row %d", col[k], i);
+      MGS_CHECK(ctx, k == rowptr[i] || col[k - 1] < col[k], MGS_ERR_INVALID, "mgs_csr_upload: columns of row %d not strictly ascending", i);
+    }
+  }
+  mgs_csr *A = nullptr;
+  MGS_TRY(mgs_csr_alloc(ctx, rows, cols, nnz, &A));
+  hipMemcpyAsync(A->rowptr, rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyHostToDevice, ctx->stream);
+  if (nnz) {
+    hipMemcpyAsync(A->col, col, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(A->val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { mgs_csr_destroy(A); return mgs_fail(ctx, MGS_ERR_HIP, "csr upload: %s", hipGetErrorString(e)); }
+  int rc = mgs_plan_csr(A);
+  if (rc != MGS_OK) { mgs_csr_destroy(A); return rc; }
+  *out = A;
+  return MGS_OK;
+}
+int mgs_csr_download(const mgs_csr *A, int *rowptr, int *col, double *val) {
+  mgs_ctx *ctx = A->ctx;
+  if (rowptr) MGS_HIP(ctx, hipMemcpyAsync(rowptr, A->rowptr, sizeof(int) * ((size_t)A->rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+  if (col && A->nnz) MGS_HIP(ctx, hipMemcpyAsync(col, A->col, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost, ctx->stream));
+  if (val && A->nnz) MGS_HIP(ctx, hipMemcpyAsync(val, A->val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MGS_OK;
+}
+int mgs_csr_shape(const mgs_csr *A, int *rows, int *cols, int64_t *nnz) {
+  if (rows) *rows = A->rows; if (cols) *cols = A->cols; if (nnz) *nnz = A->nnz;
+  return MGS_OK;
+}
+int mgs_csr_device_ptrs(const mgs_csr *A, void **rowptr, void **col, void **val) {
+  if (rowptr) *rowptr = A->rowptr; if (col) *col = A->col; if (val) *val = A->val;
+  return MGS_OK;
+}
+int mgs_csr_destroy(mgs_csr *A) {
+  if (!A) return MGS_OK;
+  if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }
+  delete A;
+  return MGS_OK;
+}
+int mgs_csr_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out) { return k_poisson3d(ctx, N, plane_lo, plane_hi, local_cols, out); }
+int mgs_csr_poisson2d(mgs_ctx *ctx, int n, mgs_csr **out) { return k_poisson2d(ctx, n, out); }
+int mgs_csr_transpose(const mgs_csr *A, mgs_csr **out) { return k_transpose(A, out); }
+int mgs_csr_galerkin(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+  MGS_CHECK(A->ctx, T->n_fine == A->rows && A->rows == A->cols, MGS_ERR_INVALID, "galerkin: A is %d x %d, P has %d rows", A->rows, A->cols, T->n_fine);
+  return T->aggregation ? k_galerkin_agg(A, T, out) : k_galerkin_general(A, T, out);
+}
+
+// ------------------------------------------------------------------ vectors
+int mgs_vec_create(mgs_ctx *ctx, int64_t n, mgs_vec **out) {
+  MGS_CHECK(ctx, n >= 0, MGS_ERR_INVALID, "mgs_vec_create: n < 0");
+  mgs_vec *v = new mgs_vec(); v->ctx = ctx; v->n = n; v->owns = true;
+  int rc = mgs_dev_alloc(ctx, &v->d, (size_t)n);
+  if (rc != MGS_OK) { delete v; return rc; }
+  hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)(n ? n : 1), ctx->stream);
+  *out = v;
+  return MGS_OK;
+}
+int mgs_vec_wrap(mgs_ctx *ctx, void *p, int64_t n, mgs_vec **out) {
+  MGS_CHECK(ctx, p || n == 0, MGS_ERR_INVALID, "mgs_vec_wrap: NULL pointer");
+  mgs_vec *v = new mgs_vec(); v->ctx = ctx; v->n = n; v->owns = false; v->d = (double *)p;
+  *out = v;
+  return MGS_OK;
+}
+int mgs_vec_destroy(mgs_vec *v) { if (!v) return MGS_OK; if (v->owns && v->d) hipFree(v->d); delete v; return MGS_OK; }
+int mgs_vec_upload(mgs_vec *v, const double *host, int64_t n) {
+  MGS_CHECK(v->ctx, n <= v->n, MGS_ERR_INVALID, "mgs_vec_upload: %lld > size %lld", (long long)n, (long long)v->n);
+  MGS_HIP(v->ctx, hipMemcpyAsync(v->d, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, v->ctx->stream));
+  MGS_HIP(v->ctx, hipStreamSynchronize(v->ctx->stream));
+  return MGS_OK;
+}
+int mgs_vec_download(const mgs_vec *v, double *host, int64_t n) {
+  MGS_CHECK(v->ctx, n <= v->n, MGS_ERR_INVALID, "mgs_vec_download: %lld > size %lld", (long long)n, (long long)v->n);
+  MGS_HIP(v->ctx, hipMemcpyAsync(host, v->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, v->ctx->stream));
+  MGS_HIP(v->ctx, hipStreamSynchronize(v->ctx->stream));
+  return MGS_OK;
+}
+int mgs_vec_fill(mgs_vec *v, double value) { return k_fill(v->ctx, v->d, v->n, value); }
+int mgs_vec_copy(const mgs_vec *src, mgs_vec *dst) {
+  MGS_CHECK(src->ctx, src->n <= dst->n, MGS_ERR_INVALID, "mgs_vec_copy: size mismatch");
+  MGS_HIP(src->ctx, hipMemcpyAsync(dst->d, src->d, sizeof(double) * (size_t)src->n, hipMemcpyDeviceToDevice, src->ctx->stream));
+  return MGS_OK;
+}
+int64_t mgs_vec_size(const mgs_vec *v) { return v->n; }
+void *mgs_vec_ptr(const mgs_vec *v) { return v->d; }
+int mgs_vec_rand(mgs_vec *v, uint64_t seed, int64_t off) { return k_rand(v->ctx, v->d, v->n, seed, off); }
+
+// ------------------------------------------------------------------ primitives
+int mgs_spmv(const mgs_csr *A, const mgs_vec *x, mgs_vec *y) {
+  MGS_CHECK(A->ctx, x->n >= A->cols && y->n >= A->rows, MGS_ERR_INVALID, "mgs_spmv: A %d x %d, x %lld, y %lld", A->rows, A->cols, (long long)x->n, (long long)y->n);
+  MGS_CHECK(A->ctx, x->d != y->d, MGS_ERR_INVALID, "mgs_spmv: y must not alias x");
+  return mgs_launch_csr_op(A, MGS_OP_SPMV, x->d, nullptr, nullptr, 0.0, y->d);
+}
+int mgs_residual(const mgs_csr *A, const mgs_vec *x, const mgs_vec *b, mgs_vec *r) {
+  MGS_CHECK(A->ctx, x->n >= A->cols && b->n >= A->rows && r->n >= A->rows, MGS_ERR_INVALID, "mgs_residual: shape mismatch");
+  MGS_CHECK(A->ctx, x->d != r->d, MGS_ERR_INVALID, "mgs_residual: r must not alias x");
+  return mgs_launch_csr_op(A, MGS_OP_RESIDUAL, x->d, b->d, nullptr, 0.0, r->d);
+}
+int mgs_diag_inv(const mgs_csr *A, mgs_vec *dinv) {
+  MGS_CHECK(A->ctx, dinv->n >= A->rows, MGS_ERR_INVALID, "mgs_diag_inv: dinv too small");
+  int bad = 0;
+  MGS_TRY(k_diag_inv(A, dinv->d, &bad));
+  MGS_CHECK(A->ctx, bad == 0, MGS_ERR_NUMERIC, "mgs_diag_inv: %d rows have a missing or zero diagonal", bad);
+  return MGS_OK;
+}
+int mgs_jacobi(const mgs_csr *A, const mgs_vec *dinv, double omega, const mgs_vec *b, const mgs_vec *x_in, mgs_vec *x_out) {
+  MGS_CHECK(A->ctx, A->rows <= A->cols && x_in->n >= A->cols && b->n >= A->rows && x_out->n >= A->rows && dinv->n >= A->rows, MGS_ERR_INVALID, "mgs_jacobi: shape mismatch");
+  MGS_CHECK(A->ctx, x_in->d != x_out->d, MGS_ERR_INVALID, "mgs_jacobi: out of place only (x_out must not alias x_in)");
+  return mgs_launch_csr_op(A, MGS_OP_JACOBI, x_in->d, b->d, dinv->d, omega, x_out->d);
+}
+
+int mgs_xfer_create(const mgs_csr *P, mgs_xfer **out) { return k_xfer_from_csr(P, out); }
+int mgs_xfer_destroy(mgs_xfer *T) {
+  if (!T) return MGS_OK;
+  if (T->agg) hipFree(T->agg); if (T->cptr) hipFree(T->cptr); if (T->members) hipFree(T->members);
+  if (T->P) mgs_csr_destroy(T->P); if (T->Pt) mgs_csr_destroy(T->Pt);
+  delete T;
+  return MGS_OK;
+}
+int mgs_xfer_shape(const mgs_xfer *T, int *n_fine, int *n_coarse, int *is_agg) {
+  if (n_fine) *n_fine = T->n_fine; if (n_coarse) *n_coarse = T->n_coarse; if (is_agg) *is_agg = T->aggregation ? 1 : 0;
+  return MGS_OK;
+}
+int mgs_xfer_download_agg(const mgs_xfer *T, int *agg) {
+  MGS_CHECK(T->ctx, T->aggregation, MGS_ERR_STATE, "transfer is not in aggregation form");
+  MGS_HIP(T->ctx, hipMemcpyAsync(agg, T->agg, sizeof(int) * (size_t)T->n_fine, hipMemcpyDeviceToHost, T->ctx->stream));
+  MGS_HIP(T->ctx, hipStreamSynchronize(T->ctx->stream));
+  return MGS_OK;
+}
+int mgs_restrict(const mgs_xfer *T, const mgs_vec *r, mgs_vec *rc) {
+  MGS_CHECK(T->ctx, r->n >= T->n_fine && rc->n >= T->n_coarse, MGS_ERR_INVALID, "mgs_restrict: shape mismatch");
+  if (T->aggregation) return k_restrict_agg(T->ctx, T->n_coarse, T->cptr, T->members, r->d, rc->d);
+  return mgs_launch_csr_op(T->Pt, MGS_OP_SPMV, r->d, nullptr, nullptr, 0.0, rc->d);
+}
+int mgs_prolong(const mgs_xfer *T, const mgs_vec *ec, mgs_vec *e) {
+  MGS_CHECK(T->ctx, e->n >= T->n_fine && ec->n >= T->n_coarse, MGS_ERR_INVALID, "mgs_prolong: shape mismatch");
+  if (T->aggregation) return k_prolong_agg(T->ctx, T->n_fine, T->agg, ec->d, e->d, 0);
+  return mgs_launch_csr_op(T->P, MGS_OP_SPMV, ec->d, nullptr, nullptr, 0.0, e->d);
+}
+
+int mgs_dot(const mgs_vec *x, const mgs_vec *y, double *out) {
+  MGS_CHECK(x->ctx, x->n == y->n, MGS_ERR_INVALID, "mgs_dot: size mismatch");
+  return k_dot(x->ctx, x->n, x->d, y->d, out);
+}
+int mgs_nrm2(const mgs_vec *x, double *out) { double s = 0; MGS_TRY(k_dot(x->ctx, x->n, x->d, x->d, &s)); *out = std::sqrt(s); return MGS_OK; }
+int mgs_axpby(double a, const mgs_vec *x, double b, mgs_vec *y) {
+  MGS_CHECK(x->ctx, x->n == y->n, MGS_ERR_INVALID, "mgs_axpby: size mismatch");
+  return k_axpby(x->ctx, x->n, a, x->d, b, y->d);
+}
+int mgs_axpbypcz(double a, const mgs_vec *x, double b, const mgs_vec *y, double c, mgs_vec *z) {
+  MGS_CHECK(x->ctx, x->n == y->n && x->n == z->n, MGS_ERR_INVALID, "mgs_axpbypcz: size mismatch");
+  return k_axpbypcz(x->ctx, x->n, a, x->d, b, y->d, c, z->d);
+}
+int mgs_halo_pack(mgs_ctx *ctx, const mgs_vec *x, const int *send_idx_dev, int64_t n_send, double *send_buf_dev) {
+  return k_gather(ctx, x->d, send_idx_dev, n_send, send_buf_dev);
+}
+
+}  // extern "C"
+
+// prolong_add for the general form needs a temporary: e = P ec; x += e
+static int prolong_add_impl(const mgs_xfer *T, const double *ec, double *x, double *tmp) {
+  if (T->aggregation) return k_prolong_agg(T->ctx, T->n_fine, T->agg, ec, x, 1);
+  MGS_TRY(mgs_launch_csr_op(T->P, MGS_OP_SPMV, ec, nullptr, nullptr, 0.0, tmp));
+  return k_axpby(T->ctx, T->n_fine, 1.0, tmp, 1.0, x);
+}
+
+extern "C" int mgs_prolong_add(const mgs_xfer *T, const mgs_vec *ec, mgs_vec *x) {
+  MGS_CHECK(T->ctx, x->n >= T->n_fine && ec->n >= T->n_coarse, MGS_ERR_INVALID, "mgs_prolong_add: shape mismatch");
+  if (T->aggregation) return k_prolong_agg(T->ctx, T->n_fine, T->agg, ec->d, x->d, 1);
+  mgs_vec *tmp = nullptr;
+  MGS_TRY(mgs_vec_create(T->ctx, T->n_fine, &tmp));
+  int rc = prolong_add_impl(T, ec->d, x->d, tmp->d);
+  hipStreamSynchronize(T->ctx->stream);
+  mgs_vec_destroy(tmp);
+  return rc;
+}
+
+// ------------------------------------------------------------------ hierarchy
+static int level_init(mgs_hier *h, mgs_level &L, const mgs_csr *A, bool own) {
+  mgs_ctx *ctx = h->ctx;
+  L.A = A; L.own_A = own; L.n = A->rows; L.n_ext = A->cols > A->rows ? A->cols : A->rows;
+  MGS_TRY(mgs_vec_create(ctx, L.n, &L.dinv));
+  MGS_TRY(mgs_vec_create(ctx, L.n_ext, &L.r));
+  MGS_TRY(mgs_vec_create(ctx, L.n_ext, &L.tmp));
+  MGS_TRY(mgs_vec_create(ctx, L.n_ext, &L.b)); MGS_TRY(mgs_vec_create(ctx, L.n_ext, &L.x));
+  return mgs_diag_inv(A, L.dinv);
+}
+static void level_free(mgs_level &L) {
+  if (L.own_A && L.A) mgs_csr_destroy(const_cast<mgs_csr *>(L.A));
+  if (L.T) mgs_xfer_destroy(L.T);
+  mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x);
+  L = mgs_level();
+}
+static void drop_graph(mgs_hier *h) {
+  if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+  h->graph_b = nullptr; h->graph_x = nullptr; h->graph_zero = -1;
+}
+
+extern "C" {
+
+int mgs_hier_create(mgs_ctx *ctx, const mgs_csr *A, double omega, int nu1, int nu2, mgs_hier **out) {
+  MGS_CHECK(ctx, A && out, MGS_ERR_INVALID, "mgs_hier_create: NULL argument");
+  MGS_CHECK(ctx, A->rows <= A->cols && A->rows > 0, MGS_ERR_INVALID, "mgs_hier_create: operator must have rows <= cols (square, or a row shard with halo columns); got %d x %d", A->rows, A->cols);
+  MGS_CHECK(ctx, nu1 >= 0 && nu2 >= 0, MGS_ERR_INVALID, "mgs_hier_create: negative sweep count");
+  mgs_hier *h = new mgs_hier();
+  h->ctx = ctx; h->omega = omega; h->nu1 = nu1; h->nu2 = nu2;
+  h->lev.emplace_back();
+  int rc = level_init(h, h->lev.back(), A, false);
+  if (rc != MGS_OK) { mgs_hier_destroy(h); return rc; }
+  *out = h;
+  return MGS_OK;
+}
+int mgs_hier_destroy(mgs_hier *h) {
+  if (!h) return MGS_OK;
+  hipStreamSynchronize(h->ctx->stream);
+  drop_graph(h);
+  for (auto &L : h->lev) level_free(L);
+  if (h->inv) hipFree(h->inv);
+  delete h;
+  return MGS_OK;
+}
+int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2) {
+  MGS_CHECK(h->ctx, nu1 >= 0 && nu2 >= 0, MGS_ERR_INVALID, "negative sweep count");
+  h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; drop_graph(h);
+  return MGS_OK;
+}
+int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user) { h->halo = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
+int mgs_hier_nlev(const mgs_hier *h) { return (int)h->lev.size(); }
+int mgs_hier_level_shape(const mgs_hier *h, int l, int *rows, int64_t *nnz) {
+  MGS_CHECK(h->ctx, l >= 0 && l < (int)h->lev.size(), MGS_ERR_INVALID, "level %d out of range", l);
+  if (rows) *rows = h->lev[l].A->rows; if (nnz) *nnz = h->lev[l].A->nnz;
+  return MGS_OK;
+}
+const mgs_csr *mgs_hier_level_A(const mgs_hier *h, int l) { return (l >= 0 && l < (int)h->lev.size()) ? h->lev[l].A : nullptr; }
+const mgs_xfer *mgs_hier_level_P(const mgs_hier *h, int l) { return (l >= 0 && l < (int)h->lev.size()) ? h->lev[l].T : nullptr; }
+
+static int push_level(mgs_hier *h, mgs_xfer *T, mgs_csr *Ac) {
+  h->lev.back().T = T;
+  h->lev.emplace_back();
+  int rc = level_init(h, h->lev.back(), Ac, true);
+  h->finalized = false; drop_graph(h);
+  if (h->inv) { hipFree(h->inv); h->inv = nullptr; }
+  return rc;
+}
+
+int mgs_hier_push_P(mgs_hier *h, const mgs_csr *P) {
+  mgs_ctx *ctx = h->ctx;
+  const mgs_csr *A = h->lev.back().A;
+  MGS_CHECK(ctx, A->rows == A->cols, MGS_ERR_STATE, "mgs_hier_push_P: sharded operators take their hierarchy from mgs_hier_coarsen");
+  MGS_CHECK(ctx, P->rows == A->rows, MGS_ERR_INVALID, "mgs_hier_push_P: P has %d rows, coarsest operator has %d", P->rows, A->rows);
+  MGS_CHECK(ctx, P->cols > 0, MGS_ERR_INVALID, "mgs_hier_push_P: P has no columns");
+  mgs_xfer *T = nullptr; mgs_csr *Ac = nullptr;
+  MGS_TRY(k_xfer_from_csr(P, &T));
+  int rc = mgs_csr_galerkin(A, T, &Ac);
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); return rc; }
+  return push_level(h, T, Ac);
+}
+
+int mgs_hier_coarsen(mgs_hier *h, double ktg, int npass, double tou, int coarse_rows, int max_levels) {
+  mgs_ctx *ctx = h->ctx;
+  while ((int)h->lev.size() < max_levels && h->lev.back().A->rows > coarse_rows) {
+    const mgs_csr *A = h->lev.back().A;
+    MGS_CHECK(ctx, A->rows == A->cols, MGS_ERR_STATE, "mgs_hier_coarsen: operator is not square");
+    mgs_xfer *T = nullptr; mgs_csr *Ac = nullptr;
+    MGS_TRY(k_pairwise_aggregate(A, ktg, npass, tou, &T, &Ac));
+    if (Ac->rows == 0 || Ac->rows > (int)(0.9 * A->rows)) {  // coarsening stalled (or everything in G0)
+      mgs_xfer_destroy(T); mgs_csr_destroy(Ac);
+      break;
+    }
+    MGS_TRY(push_level(h, T, Ac));
+  }
+  return MGS_OK;
+}
+
+int mgs_hier_finalize(mgs_hier *h) {
+  mgs_ctx *ctx = h->ctx;
+  const mgs_csr *Ac = h->lev.back().A;
+  MGS_CHECK(ctx, Ac->rows == Ac->cols, MGS_ERR_STATE, "coarsest operator is not square");
+  MGS_CHECK(ctx, Ac->rows <= 8192, MGS_ERR_STATE, "coarsest level has %d rows (> 8192): add levels (mgs_hier_coarsen) before finalize", Ac->rows);
+  if (h->inv) { hipFree(h->inv); h->inv = nullptr; }
+  h->nc = Ac->rows;
+  MGS_TRY(k_dense_inverse(ctx, Ac, &h->inv));
+  h->finalized = true; drop_graph(h);
+  return MGS_OK;
+}
+
+int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
+  // per level  (ν1+ν2)·Jacobi + residual + restriction + prolongation (zero-guess
+  // shortcuts on the first pre-sweep not credited), coarsest: dense inverse apply.
+  int64_t tot = 0;
+  const int L = (int)h->lev.size();
+  for (int l = 0; l < L - 1; ++l) {
+    const mgs_level &lv = h->lev[l];
+    int64_t n = lv.A->rows, nnz = lv.A->nnz, nc = h->lev[l + 1].A->rows, nnzP = lv.T ? lv.T->nnz : 0;
+    tot += (int64_t)(h->nu1 + h->nu2) * (12 * nnz + 36 * n + 4);
+    tot += 12 * nnz + 28 * n + 4;
+    tot += 4 * (nc + 1) + 12 * nnzP + 8 * nc;
+    tot += 20 * n + 8 * nc;
+  }
+  tot += (int64_t)h->nc * h->nc * 8 + 16 * (int64_t)h->nc;
+  return tot;
+}
+
+}  // extern "C"
+
+// The cycle body: pure kernel launches on ctx->stream (capturable into a hipGraph when no
+// halo callback is installed).
+//   ν1 × { x ← x + ωD⁻¹(b − Ax) };  r = b − Ax;  r_c = Pᵀr (bicg.cpp:48);  e_c = cycle(l+1, r_c) from 0
+//   (coarsest: A_c⁻¹, bicg.cpp:35-36,48);  x ← x + P e_c (bicg.cpp:48);  ν2 × { x ← x + ωD⁻¹(b − Ax) }
+// From x = 0 the first pre-sweep is x = (ωD⁻¹)b, the residual is b and x + P e_c is P e_c —
+// bit-identical shortcuts that skip one SpMV-sized pass each.
+static int halo_x(mgs_hier *h, int l, double *x) {
+  if (!h->halo) return MGS_OK;
+  int rc = h->halo(h->halo_user, l, x);
+  return rc ? mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange callback failed at level %d (%d)", l, rc) : MGS_OK;
+}
+int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const double *b, double *x);
+
+static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero_guess) {
+  mgs_ctx *ctx = h->ctx;
+  mgs_level &L = h->lev[l];
+  const int n = L.n;
+  if (l == (int)h->lev.size() - 1) return k_dense_gemv(ctx, h->nc, h->inv, b, x);
+  mgs_level &C = h->lev[l + 1];
+  // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
+  int swaps = h->nu2 + (zero_guess ? (h->nu1 > 0 ? h->nu1 - 1 : 0) : h->nu1);
+  double *cur = x, *alt = L.tmp->d;
+  if (zero_guess && (swaps & 1)) { cur = L.tmp->d; alt = x; }
+  bool zero = zero_guess;
+  for (int s = 0; s < h->nu1; ++s) {
+    if (zero) { MGS_TRY(k_jacobi_zero(ctx, n, h->omega, L.dinv->d, b, cur)); zero = false; }
+    else {
+      MGS_TRY(halo_x(h, l, cur));
+      MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
+      std::swap(cur, alt);
+    }
+  }
+  const double *r = L.r->d;
+  if (zero) r = b;                                       // r = b − A·0
+  else { MGS_TRY(halo_x(h, l, cur)); MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_RESIDUAL, cur, b, nullptr, 0.0, L.r->d)); }
+  // restriction
+  if (L.T->aggregation) MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, r, C.b->d));
+  else MGS_TRY(mgs_launch_csr_op(L.T->Pt, MGS_OP_SPMV, r, nullptr, nullptr, 0.0, C.b->d));
+  MGS_TRY(cycle_level(h, l + 1, C.b->d, C.x->d, true));
+  // prolongation / correction
+  if (L.T->aggregation) MGS_TRY(k_prolong_agg(ctx, n, L.T->agg, C.x->d, cur, zero ? 0 : 1));
+  else if (zero) MGS_TRY(mgs_launch_csr_op(L.T->P, MGS_OP_SPMV, C.x->d, nullptr, nullptr, 0.0, cur));
+  else {
+    MGS_TRY(mgs_launch_csr_op(L.T->P, MGS_OP_SPMV, C.x->d, nullptr, nullptr, 0.0, L.r->d));
+    MGS_TRY(k_axpby(ctx, n, 1.0, L.r->d, 1.0, cur));
+  }
+  for (int s = 0; s < h->nu2; ++s) {
+    MGS_TRY(halo_x(h, l, cur));
+    MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
+    std::swap(cur, alt);
+  }
+  if (cur != x) MGS_HIP(ctx, hipMemcpyAsync(x, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  return MGS_OK;
+}
+
+extern "C" {
+
+int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
+  mgs_ctx *ctx = h->ctx;
+  MGS_CHECK(ctx, h->finalized, MGS_ERR_STATE, "mgs_vcycle: call mgs_hier_finalize first");
+  mgs_level &L0 = h->lev[0];
+  MGS_CHECK(ctx, b->n >= L0.n && x->n >= L0.n, MGS_ERR_INVALID, "mgs_vcycle: vectors shorter than the operator (%d rows)", L0.n);
+  MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
+  if (h->lev.size() == 1) return k_dense_gemv(ctx, h->nc, h->inv, b->d, x->d);
+  // sharded level 0 needs halo room behind the owned entries: work in the level's own buffer
+  double *xw = x->d;
+  const bool staged = x->n < L0.n_ext;
+  if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
+  const bool use_graph = ctx->opt_graph && !h->halo;
+  if (!use_graph) {
+    MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
+  } else {
+    if (!(h->graph && h->graph_b == b->d && h->graph_x == xw && h->graph_zero == (zero_guess != 0))) {
+      drop_graph(h);
+      hipGraph_t g = nullptr;
+      MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      int rc = cycle_level(h, 0, b->d, xw, zero_guess != 0);
+      hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+      if (rc != MGS_OK) { if (g) hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (e != hipSuccess) { h->graph = nullptr; return mgs_fail(ctx, MGS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+      h->graph_b = b->d; h->graph_x = xw; h->graph_zero = zero_guess != 0;
+    }
+    MGS_HIP(ctx, hipGraphLaunch(h->graph, ctx->stream));
+  }
+  if (staged) MGS_HIP(ctx, hipMemcpyAsync(x->d, xw, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream));
+  return MGS_OK;
+}
+
+// BiCGSTABiml, reference src/common/bicg.cpp:74-136, statement by statement on device vectors.
+int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int *max_iter, double *tol, int *status) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, max_iter && tol && status, MGS_ERR_INVALID, "mgs_bicgstab: NULL out parameter");
+  const int n = A->rows, next = A->cols > n ? A->cols : n;
+  MGS_CHECK(ctx, x->n >= n && b->n >= n, MGS_ERR_INVALID, "mgs_bicgstab: vectors shorter than %d", n);
+  mgs_vec *p = 0, *phat = 0, *s = 0, *shat = 0, *t = 0, *v = 0, *r = 0, *rt = 0, *xe = 0;
+  struct Guard { std::vector<mgs_vec **> vs; ~Guard() { for (auto q : vs) mgs_vec_destroy(*q); } } guard;
+  for (mgs_vec **q : {&p, &phat, &s, &shat, &t, &v, &r, &rt}) { MGS_TRY(mgs_vec_create(ctx, q == &phat || q == &shat ? next : n, q)); guard.vs.push_back(q); }
+  // views of the owned part so BLAS-1 sizes agree
+  auto view = [&](mgs_vec *full, mgs_vec &out) { out.ctx = ctx; out.n = n; out.d = full->d; out.owns = false; };
+  mgs_vec xv, bv, phv, shv; view(x, xv); view(const_cast<mgs_vec *>(b), bv); view(phat, phv); view(shat, shv);
+  const mgs_vec *xin = x;
+  if (x->n < next) { MGS_TRY(mgs_vec_create(ctx, next, &xe)); guard.vs.push_back(&xe); MGS_TRY(mgs_vec_copy(&xv, xe)); xin = xe; }
+  auto halo0 = [&](mgs_vec *w) -> int { return (h && h->halo) ? h->halo(h->halo_user, 0, w->d) : 0; };
+  auto precond = [&](const mgs_vec *in, mgs_vec *out) -> int {       // M.solve (bicg.cpp:106,116)
+    if (!h) { mgs_vec ov; view(out, ov); return mgs_vec_copy(in, &ov); }
+    return mgs_vcycle(h, in, out, 1);
+  };
+  double rho_1 = 0, rho_2 = 0, alpha = 0, beta = 0, omega = 0, resid = 0, normb = 0, tmp = 0, tmp2 = 0;
+  MGS_TRY(mgs_nrm2(&bv, &normb));                                                     // :80
+  if (halo0(const_cast<mgs_vec *>(xin))) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
+  MGS_TRY(mgs_residual(A, xin, &bv, r));                                              // :82
+  MGS_TRY(mgs_vec_copy(r, rt));                                                       // :83
+  if (normb == 0.0) normb = 1;                                                        // :85-86
+  MGS_TRY(mgs_nrm2(r, &tmp));
+  if ((resid = tmp / normb) <= *tol) { *tol = resid; *max_iter = 0; *status = 0; return MGS_OK; }   // :88-92
+  for (int i = 1; i <= *max_iter; ++i) {                                              // :94
+    MGS_TRY(mgs_dot(rt, r, &rho_1));                                                  // :95
+    if (rho_1 == 0) { MGS_TRY(mgs_nrm2(r, &tmp)); *tol = tmp / normb; *status = 2; return MGS_OK; }   // :96-99
+    if (i == 1) MGS_TRY(mgs_vec_copy(r, p));                                          // :100-101
+    else {
+      beta = (rho_1 / rho_2) * (alpha / omega);                                       // :103
+      MGS_TRY(mgs_axpbypcz(1.0, r, -beta * omega, v, beta, p));                       // :104
+    }
+    MGS_TRY(precond(p, phat));                                                        // :106
+    if (halo0(phat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
+    MGS_TRY(mgs_spmv(A, phat, v));                                                    // :107
+    MGS_TRY(mgs_dot(rt, v, &tmp)); alpha = rho_1 / tmp;                               // :108
+    MGS_TRY(mgs_axpbypcz(1.0, r, -alpha, v, 0.0, s));                                 // :109
+    MGS_TRY(mgs_nrm2(s, &tmp));
+    if ((resid = tmp / normb) < *tol) {                                               // :110-115
+      MGS_TRY(mgs_axpby(alpha, &phv, 1.0, &xv));
+      *max_iter = i; *tol = resid; *status = 0; return mgs_sync(ctx);
+    }
+    MGS_TRY(precond(s, shat));                                                        // :116
+    if (halo0(shat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
+    MGS_TRY(mgs_spmv(A, shat, t));                                                    // :117
+    MGS_TRY(mgs_dot(t, s, &tmp)); MGS_TRY(mgs_dot(t, t, &tmp2)); omega = tmp / tmp2;  // :118
+    MGS_TRY(mgs_axpbypcz(alpha, &phv, omega, &shv, 1.0, &xv));                        // :119
+    MGS_TRY(mgs_axpbypcz(1.0, s, -omega, t, 0.0, r));                                 // :120
+    rho_2 = rho_1;                                                                    // :122
+    MGS_TRY(mgs_nrm2(r, &tmp));
+    if ((resid = tmp / normb) < *tol) { *tol = resid; *max_iter = i; *status = 0; return mgs_sync(ctx); }   // :123-127
+    if (omega == 0) { *tol = resid; *status = 3; return mgs_sync(ctx); }              // :128-131
+  }
+  *tol = resid; *status = 1;                                                          // :134-135
+  return mgs_sync(ctx);
+}
+
+// ------------------------------------------------------------------ instrumentation
+int mgs_time_kernel(const mgs_csr *A, int op, const mgs_vec *x, const mgs_vec *b, const mgs_vec *dinv, mgs_vec *out, int reps, double *ms) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, reps > 0 && ms && x && out, MGS_ERR_INVALID, "mgs_time_kernel: bad arguments");
+  MGS_CHECK(ctx, op == MGS_OP_SPMV || (b && (op == MGS_OP_RESIDUAL || dinv)), MGS_ERR_INVALID, "mgs_time_kernel: missing operand");
+  hipEvent_t e0, e1;
+  MGS_HIP(ctx, hipEventCreate(&e0)); MGS_HIP(ctx, hipEventCreate(&e1));
+  MGS_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i)
+    MGS_TRY(mgs_launch_csr_op(A, op, x->d, b ? b->d : nullptr, dinv ? dinv->d : nullptr, 0.6, out->d));
+  MGS_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  MGS_HIP(ctx, hipEventSynchronize(e1));
+  float t = 0; MGS_HIP(ctx, hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms = (double)t / reps;
+  return MGS_OK;
+}
+int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double *ms) {
+  mgs_ctx *ctx = h->ctx;
+  MGS_CHECK(ctx, reps > 0 && ms, MGS_ERR_INVALID, "mgs_time_vcycle: bad arguments");
+  hipEvent_t e0, e1;
+  MGS_HIP(ctx, hipEventCreate(&e0)); MGS_HIP(ctx, hipEventCreate(&e1));
+  MGS_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i) MGS_TRY(mgs_vcycle(h, b, x, 1));
+  MGS_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  MGS_HIP(ctx, hipEventSynchronize(e1));
+  float t = 0; MGS_HIP(ctx, hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms = (double)t / reps;
+  return MGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// mgs_internal.hpp — private structures of libmgs.so (gfx950 only; no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgs.h"
+
+struct mgs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // scratch for reductions (device partials + pinned host landing zone)
+  double *red_dev = nullptr;
+  double *red_host = nullptr;
+  int red_cap = 0;
+  int n_cu = 256;
+  // options
+  int opt_xcd_remap = 1;
+  int opt_nontemporal = 1;
+  int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
+  int opt_graph = 1;
+  mgs_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+};
+
+struct mgs_csr {
+  mgs_ctx *ctx = nullptr;
+  int rows = 0, cols = 0;
+  int64_t nnz = 0;
+  int *rowptr = nullptr;  // rows+1
+  int *col = nullptr;     // nnz (+pad)
+  double *val = nullptr;  // nnz (+pad)
+  bool owns = true;
+  // launch plan of the row-block stream kernel (computed at upload)
+  int max_row_len = 0;
+  int lds_cap = 0;  // products staged per block (doubles)
+};
+
+struct mgs_vec {
+  mgs_ctx *ctx = nullptr;
+  int64_t n = 0;
+  double *d = nullptr;
+  bool owns = true;
+};
+
+struct mgs_xfer {
+  mgs_ctx *ctx = nullptr;
+  int n_fine = 0, n_coarse = 0;
+  bool aggregation = false;
+  // aggregation form
+  int *agg = nullptr;      // n_fine, -1 = not aggregated (G0)
+  int *cptr = nullptr;     // n_coarse+1: member list offsets (Pᵀ rowptr)
+  int *members = nullptr;  // nnz(P): fine rows sorted by aggregate (Pᵀ col)
+  int64_t nnz = 0;
+  // general form
+  mgs_csr *P = nullptr, *Pt = nullptr;
+};
+
+struct mgs_level {
+  const mgs_csr *A = nullptr;
+  bool own_A = false;
+  mgs_xfer *T = nullptr;  // to next level
+  int n = 0;              // owned rows
+  int n_ext = 0;          // owned + halo
+  mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
+  mgs_vec *b = nullptr, *x = nullptr;  // coarse-level rhs / solution (levels >= 1)
+};
+
+struct mgs_hier {
+  mgs_ctx *ctx = nullptr;
+  std::vector<mgs_level> lev;
+  double omega = 0.5;
+  int nu1 = 1, nu2 = 1;
+  bool finalized = false;
+  // coarsest direct solve
+  int nc = 0;
+  double *inv = nullptr;  // nc*nc dense inverse (row-major)
+  mgs_halo_fn halo = nullptr;
+  void *halo_user = nullptr;
+  // hipGraph cache of one V-cycle
+  hipGraphExec_t graph = nullptr;
+  const double *graph_b = nullptr;
+  double *graph_x = nullptr;
+  int graph_zero = -1;
+};
+
+// ------------------------------------------------------------------ error plumbing
+extern thread_local std::string g_mgs_last_error;
+int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...);
+
+#define MGS_HIP(ctx, call)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return mgs_fail((ctx), MGS_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                      hipGetErrorString(e_), __FILE__, __LINE__);                       \
+  } while (0)
+
+#define MGS_CHECK(ctx, cond, code, ...)                                                 \
+  do {                                                                                  \
+    if (!(cond)) return mgs_fail((ctx), (code), __VA_ARGS__);                           \
+  } while (0)
+
+#define MGS_TRY(expr)                                                                   \
+  do {                                                                                  \
+    int rc_ = (expr);                                                                   \
+    if (rc_ != MGS_OK) return rc_;                                                      \
+  } while (0)
+
+// ------------------------------------------------------------------ kernel launchers
+// (kernels_spmv.hip)
+enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2 };
+int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b,
+                      const double *dinv, double omega, double *out);
+int mgs_plan_csr(mgs_csr *A);
+// (kernels_aux.hip)
+int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
+int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc);
+int k_prolong_agg(mgs_ctx *ctx, int n, const int *agg, const double *ec, double *x, int add);
+int k_fill(mgs_ctx *ctx, double *d, int64_t n, double v);
+int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off);
+int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double *y);
+int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z);
+int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host);
+int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *x);
+int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out);
+int k_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out);
+int k_poisson2d(mgs_ctx *ctx, int n, mgs_csr **out);
+int k_gather(mgs_ctx *ctx, const double *x, const int *idx, int64_t n, double *out);
+int k_xfer_from_csr(const mgs_csr *P, mgs_xfer **out);
+int k_transpose(const mgs_csr *A, mgs_csr **out);
+// (setup_agmg.hip)
+int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host);
+int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
+int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
+int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out);
+
+// helpers (mgs_api.hip)
+int mgs_csr_alloc(mgs_ctx *ctx, int rows, int cols, int64_t nnz, mgs_csr **out);
+template <class T>
+static inline int mgs_dev_alloc(mgs_ctx *ctx, T **p, size_t count) {
+  *p = nullptr;
+  hipError_t e = hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
+  if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_ALLOC, "hipMalloc(%zu bytes): %s", sizeof(T) * count, hipGetErrorString(e));
+  return MGS_OK;
+}
+static inline int mgs_grid(int64_t work, int block) { return (int)((work + block - 1) / block); }

@@ -1,0 +1,573 @@
+// setup_agmg.hip — on-device hierarchy setup (needed by configs 3 and 5):
+//   * own exclusive scan (the reference used cub::DeviceScan, src/GPU_CUDAC++/PrefixSum.cu:6-21)
+//   * CSR transpose / aggregate member lists (reference: cusparseCsr2cscEx2,
+//     src/GPU_CUDAC++/MatrixOperations.cu:388-456)
+//   * Galerkin product A_c = PᵀAP specialised for 0/1 aggregation P:
+//     A_c[agg i, agg j] += a_ij, sort + reduce by key per coarse row (reference: two
+//     cusparseSpGEMM calls, src/GPU_CUDAC++/main.cu:251-253; CPU: bicg.cpp:33)
+//   * Notay pairwise aggregation (src/CPU_C++/AGMG.cpp:101-315;
+//     src/GPU_CUDAC++/Aggregation.cu:17-270) with a DETERMINISTIC matching: instead of the
+//     reference GPU's race-dependent atomicCAS claim (Aggregation.cu:203) every undecided
+//     node picks its best admissible neighbour from a snapshot and mutual picks pair up
+//     (locally-dominant edges), so P is reproducible run to run.
+// FP64 throughout (the reference GPU setup is float32, MatrixIO.cu:32-36).
+#include "mgs_internal.hpp"
+
+#include <algorithm>
+
+namespace {
+constexpr int TB = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = TB * SCAN_ITEMS;
+
+// ------------------------------------------------------------------ exclusive scan (int32)
+__device__ __forceinline__ int block_exclusive_scan(int v, int *sh /*TB/64+1*/, int *total) {
+  // wave inclusive scan
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+  for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < TB / 64; ++i) { int t = sh[i]; sh[i] = run; run += t; } sh[TB / 64] = run; }
+  __syncthreads();
+  int res = inc - v + sh[w];
+  *total = sh[TB / 64];
+  __syncthreads();
+  return res;
+}
+__global__ __launch_bounds__(TB) void scan_tile_sums(const int *__restrict__ in, int64_t n, int *__restrict__ sums) {
+  __shared__ int sh[TB / 64 + 1];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) if (base + q < n) s += in[base + q];
+  int tot; block_exclusive_scan(s, sh, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(TB) void scan_tile_apply(const int *__restrict__ in, int *__restrict__ out, int64_t n, const int *__restrict__ offs) {
+  __shared__ int sh[TB / 64 + 1];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS]; int s = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) { v[q] = (base + q < n) ? in[base + q] : 0; s += v[q]; }
+  int tot; int ex = block_exclusive_scan(s, sh, &tot);
+  int run = ex + (offs ? offs[blockIdx.x] : 0);
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+}
+
+int scan_rec(mgs_ctx *ctx, const int *in, int *out, int64_t n) {
+  if (n <= 0) return MGS_OK;
+  int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 1) {
+    hipLaunchKernelGGL(scan_tile_apply, dim3(1), dim3(TB), 0, ctx->stream, in, out, n, (const int *)nullptr);
+    MGS_HIP(ctx, hipGetLastError());
+    return MGS_OK;
+  }
+  int *sums = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &sums, (size_t)nb));
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(TB), 0, ctx->stream, in, n, sums);
+  int rc = scan_rec(ctx, sums, sums, nb);
+  if (rc == MGS_OK) {
+    hipLaunchKernelGGL(scan_tile_apply, dim3((unsigned)nb), dim3(TB), 0, ctx->stream, in, out, n, (const int *)sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "scan launch: %s", hipGetErrorString(e));
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(sums);
+  return rc;
+}
+
+// ------------------------------------------------------------------ bucket helpers
+__global__ void count_keys_kernel(int64_t n, const int *__restrict__ key, int *__restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { int k = key[i]; if (k >= 0) atomicAdd(&counts[k], 1); }
+}
+// members of aggregate a (unordered claim), then sorted per aggregate
+__global__ void fill_members_kernel(int n, const int *__restrict__ agg, const int *__restrict__ cptr, int *__restrict__ cursor, int *__restrict__ members) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int a = agg[i];
+  if (a < 0) return;
+  int p = cptr[a] + atomicAdd(&cursor[a], 1);
+  members[p] = i;
+}
+__global__ void sort_segments_kernel(int nseg, const int *__restrict__ ptr, int *__restrict__ keys, double *__restrict__ vals) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nseg) return;
+  int lo = ptr[c], hi = ptr[c + 1];
+  for (int a = lo + 1; a < hi; ++a) {
+    int k = keys[a]; double v = vals ? vals[a] : 0.0;
+    int b = a - 1;
+    while (b >= lo && keys[b] > k) { keys[b + 1] = keys[b]; if (vals) vals[b + 1] = vals[b]; --b; }
+    keys[b + 1] = k; if (vals) vals[b + 1] = v;
+  }
+}
+__global__ void csr_row_of_nnz_fill_T(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                      const int *__restrict__ tptr, int *__restrict__ cursor, int *__restrict__ tcol, double *__restrict__ tval) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    int c = col[k];
+    int p = tptr[c] + atomicAdd(&cursor[c], 1);
+    tcol[p] = i; tval[p] = val[k];
+  }
+}
+
+// P in CSR → aggregate ids; flags rows that break the aggregation form
+__global__ void p_to_agg_kernel(int n, int ncols, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                int *__restrict__ agg, int *__restrict__ bad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = rowptr[i], len = rowptr[i + 1] - lo;
+  int a = -1;
+  if (len == 1 && val[lo] == 1.0 && col[lo] >= 0 && col[lo] < ncols) a = col[lo];
+  else if (len != 0) atomicAdd(bad, 1);
+  agg[i] = a;
+}
+
+// ------------------------------------------------------------------ Galerkin (aggregation P)
+__global__ void galerkin_ub_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ rowptr, int *__restrict__ ub) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nc) return;
+  int s = 0;
+  if (c < nc) for (int k = cptr[c]; k < cptr[c + 1]; ++k) { int i = members[k]; s += rowptr[i + 1] - rowptr[i]; }
+  ub[c] = s;
+}
+// one lane per coarse row: gather (agg(col), val) of all member rows, insertion-sort by
+// coarse column (stable: fine order i↑, j↑ inside a key), then reduce equal keys in place.
+__global__ void galerkin_fill_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg,
+                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                     const int *__restrict__ offs, int *__restrict__ scol, double *__restrict__ sval, int *__restrict__ uniq) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nc) return;
+  if (c == nc) { uniq[c] = 0; return; }
+  const int base = offs[c];
+  int cnt = 0;
+  for (int m = cptr[c]; m < cptr[c + 1]; ++m) {
+    int i = members[m];
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      int a = agg[col[k]];
+      if (a < 0) continue;
+      double v = val[k];
+      int b = base + cnt - 1;
+      while (b >= base && scol[b] > a) { scol[b + 1] = scol[b]; sval[b + 1] = sval[b]; --b; }
+      scol[b + 1] = a; sval[b + 1] = v;
+      ++cnt;
+    }
+  }
+  int w = 0;
+  for (int r = 0; r < cnt;) {
+    int key = scol[base + r]; double s = sval[base + r]; ++r;
+    while (r < cnt && scol[base + r] == key) { s += sval[base + r]; ++r; }
+    scol[base + w] = key; sval[base + w] = s; ++w;
+  }
+  uniq[c] = w;
+}
+__global__ void galerkin_copy_kernel(int nc, const int *__restrict__ offs, const int *__restrict__ crowptr, const int *__restrict__ scol,
+                                     const double *__restrict__ sval, int *__restrict__ ccol, double *__restrict__ cval) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  int src = offs[c], dst = crowptr[c], len = crowptr[c + 1] - dst;
+  for (int q = 0; q < len; ++q) { ccol[dst + q] = scol[src + q]; cval[dst + q] = sval[src + q]; }
+}
+
+// ------------------------------------------------------------------ pairwise aggregation
+__device__ __forceinline__ double csr_lookup(const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int i, int j) {
+  int lo = rowptr[i], hi = rowptr[i + 1] - 1;   // reference getElementMatrixCSR, MatrixAccess.cu:28-47
+  while (lo <= hi) {
+    int mid = (lo + hi) >> 1; int c = col[mid];
+    if (c == j) return val[mid];
+    if (c < j) lo = mid + 1; else hi = mid - 1;
+  }
+  return 0.0;
+}
+__global__ void pattern_asym_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int *__restrict__ asym) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int bad = 0;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    int j = col[k];
+    if (j == i) continue;
+    int lo = rowptr[j], hi = rowptr[j + 1] - 1; bool found = false;
+    while (lo <= hi) { int mid = (lo + hi) >> 1; int c = col[mid]; if (c == i) { found = true; break; } if (c < i) lo = mid + 1; else hi = mid - 1; }
+    if (!found) ++bad;
+  }
+  if (bad) atomicAdd(asym, bad);
+}
+// per node: a_ii, s_i = −Σ_{j≠i}(a_ij+a_ji)/2 (AGMG.cpp:84-90, Aggregation.cu:68-90) and the G0
+// test a_ii ≥ ktg/(ktg−2)·Σ_{j≠i}|a_ij+a_ji|/2 on the first pass (AGMG.cpp:118-123,
+// Aggregation.cu:17-64).  With At == nullptr the pattern is symmetric and a_ji is looked up.
+__global__ void agg_node_stats_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                      const int *__restrict__ trowptr, const int *__restrict__ tcol, const double *__restrict__ tval,
+                                      double ktg, int first_pass, double *__restrict__ diag, double *__restrict__ s, int *__restrict__ state) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double aii = 0.0, ssum = 0.0, asum = 0.0;
+  if (trowptr == nullptr) {
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      int j = col[k]; double aij = val[k];
+      if (j == i) { aii = aij; continue; }
+      double aji = csr_lookup(rowptr, col, val, j, i);
+      ssum += (aij + aji) / 2; asum += fabs((aij + aji) / 2);
+    }
+  } else {
+    int r = rowptr[i], re = rowptr[i + 1], c = trowptr[i], ce = trowptr[i + 1];
+    while (r < re || c < ce) {
+      int jr = r < re ? col[r] : 0x7fffffff, jc = c < ce ? tcol[c] : 0x7fffffff;
+      int j = min(jr, jc);
+      double aij = 0.0, aji = 0.0;
+      if (jr == j) aij = val[r++];
+      if (jc == j) aji = tval[c++];
+      if (j == i) { aii = aij; continue; }
+      ssum += (aij + aji) / 2; asum += fabs((aij + aji) / 2);
+    }
+  }
+  diag[i] = aii; s[i] = -ssum;
+  int g0 = first_pass && (aii >= (ktg / (ktg - 2)) * asum);
+  state[i] = g0 ? -2 : -1;
+}
+// μ({i,j}) per stored entry (AGMG.cpp:92-99, Aggregation.cu:96-105), +inf if the pair is not
+// admissible: j==i, a_ij==0, i or j in G0, a_ii−s_i+a_jj−s_j<0 (`okay`, Aggregation.cu:157-159),
+// μ≤0 or μ>ktg (AGMG.cpp:163,171).
+__global__ void agg_edge_weight_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                       const double *__restrict__ diag, const double *__restrict__ s, const int *__restrict__ state,
+                                       double ktg, double *__restrict__ w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double aii = diag[i], si = s[i];
+  const bool gi = state[i] == -2;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    int j = col[k]; double aij = val[k];
+    double wk = INFINITY;
+    if (j != i && aij != 0.0 && !gi && state[j] != -2) {
+      double ajj = diag[j], sj = s[j];
+      if (aii - si + ajj - sj >= 0) {
+        double aji = csr_lookup(rowptr, col, val, j, i);
+        double num = 2 / (1 / aii + 1 / ajj);
+        double den = (-(aij + aji) / 2) + 1 / (1 / (aii - si) + 1 / (ajj - sj));
+        double mu = num / den;
+        if (mu > 0 && mu <= ktg) wk = mu;
+      }
+    }
+    w[k] = wk;
+  }
+}
+struct EdgeKey { double w; int d; int par; unsigned h; int mn; };
+__device__ __forceinline__ unsigned edge_hash(unsigned a, unsigned b) {
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+// Tie-break among equal μ (a pure heuristic, symmetric in (i,j)): nearest index first, then
+// the edge whose lower end is an even multiple of the stride — on lexicographically numbered
+// grids this yields aligned pairs (2m,2m+1), i.e. the regular semi-coarsening the sequential
+// reference produces (AGMG.cpp:149-179 scans neighbours in ascending order) — then a hash.
+__device__ __forceinline__ EdgeKey make_key(double w, int i, int j, int hash_only) {
+  EdgeKey k; int mn = min(i, j), mx = max(i, j);
+  k.w = hash_only ? 0.0 : w; k.d = hash_only ? 0 : mx - mn; k.par = hash_only ? 0 : ((mn / (mx - mn)) & 1);
+  k.h = edge_hash((unsigned)mn, (unsigned)mx); k.mn = mn;
+  return k;
+}
+__device__ __forceinline__ bool key_less(const EdgeKey &a, const EdgeKey &b) {
+  if (a.w != b.w) return a.w < b.w;
+  if (a.d != b.d) return a.d < b.d;
+  if (a.par != b.par) return a.par < b.par;
+  if (a.h != b.h) return a.h < b.h;
+  return a.mn < b.mn;
+}
+__global__ void agg_pick_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ w,
+                                const int *__restrict__ state, int hash_only, int *__restrict__ pick) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (state[i] != -1) { pick[i] = -3; return; }
+  int best = -1; EdgeKey bk;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+    double wk = w[k];
+    if (!(wk < INFINITY)) continue;
+    int j = col[k];
+    if (state[j] != -1) continue;
+    EdgeKey key = make_key(wk, i, j, hash_only);
+    if (best < 0 || key_less(key, bk)) { best = j; bk = key; }
+  }
+  pick[i] = best;
+}
+__global__ void agg_match_kernel(int n, const int *__restrict__ pick, int *__restrict__ state, int force_single, int *__restrict__ counters /*[0]=undecided left*/) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int p = pick[i];
+  if (p == -3) return;
+  if (p == -1) { state[i] = i; return; }            // no admissible free neighbour: singleton (AGMG.cpp:175-178)
+  if (pick[p] == i) { state[i] = p; return; }       // mutual pick: pair (AGMG.cpp:171-174)
+  if (force_single) { state[i] = i; return; }
+  atomicAdd(&counters[0], 1);
+}
+__global__ void agg_leader_flag_kernel(int n, const int *__restrict__ state, int *__restrict__ flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  flag[i] = (i < n && state[i] >= i) ? 1 : 0;         // leader = lower end of a pair or a singleton (Aggregation.cu:214-225)
+}
+__global__ void agg_assign_kernel(int n, const int *__restrict__ state, const int *__restrict__ ids, int *__restrict__ agg) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int st = state[i];
+  agg[i] = st < 0 ? -1 : ids[min(i, st)];
+}
+__global__ void agg_compose_kernel(int n, int *__restrict__ agg, const int *__restrict__ agg2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int a = agg[i];
+  agg[i] = a < 0 ? -1 : agg2[a];
+}
+
+struct DevBuf {  // RAII for setup temporaries
+  void *p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  template <class T> T *as() { return (T *)p; }
+};
+template <class T>
+int dalloc(mgs_ctx *ctx, DevBuf &b, size_t count) { T *q = nullptr; MGS_TRY(mgs_dev_alloc(ctx, &q, count)); b.p = q; return MGS_OK; }
+
+// build cptr/members from agg (device array of n_fine entries, -1 = none)
+int build_member_lists(mgs_ctx *ctx, int n, int nc, const int *agg, int **cptr_out, int **members_out, int64_t *nnz_out) {
+  int *cptr = nullptr, *members = nullptr; DevBuf cursor;
+  MGS_TRY(mgs_dev_alloc(ctx, &cptr, (size_t)nc + 1));
+  MGS_HIP(ctx, hipMemsetAsync(cptr, 0, sizeof(int) * ((size_t)nc + 1), ctx->stream));
+  if (n) hipLaunchKernelGGL(count_keys_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, (int64_t)n, agg, cptr);
+  MGS_TRY(scan_rec(ctx, cptr, cptr, (int64_t)nc + 1));
+  int total = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&total, cptr + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MGS_TRY(mgs_dev_alloc(ctx, &members, (size_t)total));
+  MGS_TRY(dalloc<int>(ctx, cursor, (size_t)nc + 1));
+  MGS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(int) * ((size_t)nc + 1), ctx->stream));
+  if (n) hipLaunchKernelGGL(fill_members_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, agg, cptr, cursor.as<int>(), members);
+  if (nc) hipLaunchKernelGGL(sort_segments_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, (double *)nullptr);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *cptr_out = cptr; *members_out = members; *nnz_out = total;
+  return MGS_OK;
+}
+
+int xfer_from_agg(mgs_ctx *ctx, int n, int nc, int *agg_owned, mgs_xfer **out) {
+  mgs_xfer *T = new mgs_xfer();
+  T->ctx = ctx; T->n_fine = n; T->n_coarse = nc; T->aggregation = true; T->agg = agg_owned;
+  int rc = build_member_lists(ctx, n, nc, agg_owned, &T->cptr, &T->members, &T->nnz);
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); return rc; }
+  *out = T;
+  return MGS_OK;
+}
+
+}  // namespace
+
+int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host) {
+  MGS_TRY(scan_rec(ctx, in, out, n));
+  if (total_host) {
+    // caller convention: in has n entries with in[n-1] == 0 as the sentinel → out[n-1] is the total
+    int t = 0;
+    MGS_HIP(ctx, hipMemcpyAsync(&t, out + (n - 1), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *total_host = t;
+  }
+  return MGS_OK;
+}
+
+int k_transpose(const mgs_csr *A, mgs_csr **out) {
+  mgs_ctx *ctx = A->ctx;
+  mgs_csr *B = nullptr;
+  MGS_TRY(mgs_csr_alloc(ctx, A->cols, A->rows, A->nnz, &B));
+  DevBuf cursor;
+  MGS_HIP(ctx, hipMemsetAsync(B->rowptr, 0, sizeof(int) * ((size_t)B->rows + 1), ctx->stream));
+  if (A->nnz) hipLaunchKernelGGL(count_keys_kernel, dim3(mgs_grid(A->nnz, TB)), dim3(TB), 0, ctx->stream, A->nnz, A->col, B->rowptr);
+  MGS_TRY(scan_rec(ctx, B->rowptr, B->rowptr, (int64_t)B->rows + 1));
+  MGS_TRY(dalloc<int>(ctx, cursor, (size_t)B->rows + 1));
+  MGS_HIP(ctx, hipMemsetAsync(cursor.p, 0, sizeof(int) * ((size_t)B->rows + 1), ctx->stream));
+  if (A->rows) hipLaunchKernelGGL(csr_row_of_nnz_fill_T, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, A->val, B->rowptr, cursor.as<int>(), B->col, B->val);
+  if (B->rows) hipLaunchKernelGGL(sort_segments_kernel, dim3(mgs_grid(B->rows, TB)), dim3(TB), 0, ctx->stream, B->rows, B->rowptr, B->col, B->val);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MGS_TRY(mgs_plan_csr(B));
+  *out = B;
+  return MGS_OK;
+}
+
+int k_xfer_from_csr(const mgs_csr *P, mgs_xfer **out) {
+  mgs_ctx *ctx = P->ctx;
+  int *agg = nullptr; DevBuf bad;
+  MGS_TRY(mgs_dev_alloc(ctx, &agg, (size_t)P->rows));
+  MGS_TRY(dalloc<int>(ctx, bad, 1));
+  MGS_HIP(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+  if (P->rows) hipLaunchKernelGGL(p_to_agg_kernel, dim3(mgs_grid(P->rows, TB)), dim3(TB), 0, ctx->stream, P->rows, P->cols, P->rowptr, P->col, P->val, agg, bad.as<int>());
+  int hbad = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hbad == 0) return xfer_from_agg(ctx, P->rows, P->cols, agg, out);
+  // general P: keep P and materialise Pᵀ (bicg.cpp:32)
+  hipFree(agg);
+  mgs_xfer *T = new mgs_xfer();
+  T->ctx = ctx; T->n_fine = P->rows; T->n_coarse = P->cols; T->aggregation = false; T->nnz = P->nnz;
+  int rc = mgs_csr_alloc(ctx, P->rows, P->cols, P->nnz, &T->P);
+  if (rc == MGS_OK) {
+    hipMemcpyAsync(T->P->rowptr, P->rowptr, sizeof(int) * ((size_t)P->rows + 1), hipMemcpyDeviceToDevice, ctx->stream);
+    hipMemcpyAsync(T->P->col, P->col, sizeof(int) * (size_t)P->nnz, hipMemcpyDeviceToDevice, ctx->stream);
+    hipMemcpyAsync(T->P->val, P->val, sizeof(double) * (size_t)P->nnz, hipMemcpyDeviceToDevice, ctx->stream);
+    rc = mgs_plan_csr(T->P);
+  }
+  if (rc == MGS_OK) rc = k_transpose(T->P, &T->Pt);
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); return rc; }
+  *out = T;
+  return MGS_OK;
+}
+
+int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows == A->cols, MGS_ERR_INVALID, "galerkin: shape mismatch");
+  const int nc = T->n_coarse;
+  DevBuf ub, uniq, scol, sval;
+  MGS_TRY(dalloc<int>(ctx, ub, (size_t)nc + 1));
+  MGS_TRY(dalloc<int>(ctx, uniq, (size_t)nc + 1));
+  hipLaunchKernelGGL(galerkin_ub_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, T->cptr, T->members, A->rowptr, ub.as<int>());
+  MGS_TRY(scan_rec(ctx, ub.as<int>(), ub.as<int>(), (int64_t)nc + 1));
+  int tot = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&tot, ub.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MGS_TRY(dalloc<int>(ctx, scol, (size_t)tot));
+  MGS_TRY(dalloc<double>(ctx, sval, (size_t)tot));
+  hipLaunchKernelGGL(galerkin_fill_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, T->cptr, T->members, T->agg, A->rowptr, A->col, A->val, ub.as<int>(), scol.as<int>(), sval.as<double>(), uniq.as<int>());
+  MGS_TRY(scan_rec(ctx, uniq.as<int>(), uniq.as<int>(), (int64_t)nc + 1));
+  int nnzc = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&nnzc, uniq.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  mgs_csr *C = nullptr;
+  MGS_TRY(mgs_csr_alloc(ctx, nc, nc, nnzc, &C));
+  MGS_HIP(ctx, hipMemcpyAsync(C->rowptr, uniq.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  if (nc) hipLaunchKernelGGL(galerkin_copy_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, ub.as<int>(), C->rowptr, scol.as<int>(), sval.as<double>(), C->col, C->val);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MGS_TRY(mgs_plan_csr(C));
+  *out = C;
+  return MGS_OK;
+}
+
+// general P (not an aggregation): host Gustavson product, as the reference does with Eigen on
+// the CPU at setup (bicg.cpp:33).  Setup only — never on the solve path.
+int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+  mgs_ctx *ctx = A->ctx;
+  auto pull = [&](const mgs_csr *M, std::vector<int> &rp, std::vector<int> &ci, std::vector<double> &v) -> int {
+    rp.resize((size_t)M->rows + 1); ci.resize((size_t)M->nnz); v.resize((size_t)M->nnz);
+    return mgs_csr_download(M, rp.data(), ci.data(), v.data());
+  };
+  std::vector<int> arp, aci, prp, pci, trp, tci; std::vector<double> av, pv, tv;
+  MGS_TRY(pull(A, arp, aci, av)); MGS_TRY(pull(T->P, prp, pci, pv)); MGS_TRY(pull(T->Pt, trp, tci, tv));
+  auto spgemm = [](int n, int m, const std::vector<int> &rp1, const std::vector<int> &c1, const std::vector<double> &v1,
+                   const std::vector<int> &rp2, const std::vector<int> &c2, const std::vector<double> &v2,
+                   std::vector<int> &rpo, std::vector<int> &co, std::vector<double> &vo) {
+    std::vector<double> acc((size_t)m, 0.0); std::vector<int> mark((size_t)m, -1);
+    rpo.assign((size_t)n + 1, 0); co.clear(); vo.clear();
+    for (int i = 0; i < n; ++i) {
+      size_t base = co.size();
+      for (int ka = rp1[i]; ka < rp1[i + 1]; ++ka) {
+        int k = c1[ka]; double a = v1[ka];
+        for (int kb = rp2[k]; kb < rp2[k + 1]; ++kb) {
+          int j = c2[kb];
+          if (mark[j] != i) { mark[j] = i; co.push_back(j); acc[j] = a * v2[kb]; } else acc[j] += a * v2[kb];
+        }
+      }
+      std::sort(co.begin() + base, co.end());
+      for (size_t q = base; q < co.size(); ++q) vo.push_back(acc[co[q]]);
+      rpo[i + 1] = (int)co.size();
+    }
+  };
+  std::vector<int> r1, c1, r2, c2; std::vector<double> v1, v2;
+  spgemm(T->n_coarse, A->cols, trp, tci, tv, arp, aci, av, r1, c1, v1);
+  spgemm(T->n_coarse, T->n_coarse, r1, c1, v1, prp, pci, pv, r2, c2, v2);
+  return mgs_csr_upload(ctx, T->n_coarse, T->n_coarse, (int64_t)c2.size(), r2.data(), c2.data(), v2.data(), out);
+}
+
+// one pairwise pass on matrix M → agg ids (device array, caller frees) and count
+static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, int **agg_out, int *nc_out) {
+  mgs_ctx *ctx = M->ctx;
+  const int n = M->rows;
+  DevBuf diag, s, state, w, pick, cnt, flag, asym;
+  MGS_TRY(dalloc<double>(ctx, diag, (size_t)n)); MGS_TRY(dalloc<double>(ctx, s, (size_t)n));
+  MGS_TRY(dalloc<int>(ctx, state, (size_t)n)); MGS_TRY(dalloc<double>(ctx, w, (size_t)M->nnz));
+  MGS_TRY(dalloc<int>(ctx, pick, (size_t)n)); MGS_TRY(dalloc<int>(ctx, cnt, 2)); MGS_TRY(dalloc<int>(ctx, flag, (size_t)n + 1));
+  MGS_TRY(dalloc<int>(ctx, asym, 1));
+  hipStream_t st = ctx->stream;
+  const dim3 g(mgs_grid(n, TB)), b(TB);
+  MGS_HIP(ctx, hipMemsetAsync(asym.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(pattern_asym_kernel, g, b, 0, st, n, M->rowptr, M->col, asym.as<int>());
+  int hasym = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&hasym, asym.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  MGS_HIP(ctx, hipStreamSynchronize(st));
+  mgs_csr *Mt = nullptr;
+  if (hasym) MGS_TRY(k_transpose(M, &Mt));
+  hipLaunchKernelGGL(agg_node_stats_kernel, g, b, 0, st, n, M->rowptr, M->col, M->val, Mt ? Mt->rowptr : nullptr, Mt ? Mt->col : nullptr,
+                     Mt ? Mt->val : nullptr, ktg, first_pass, diag.as<double>(), s.as<double>(), state.as<int>());
+  hipLaunchKernelGGL(agg_edge_weight_kernel, g, b, 0, st, n, M->rowptr, M->col, M->val, diag.as<double>(), s.as<double>(), state.as<int>(), ktg, w.as<double>());
+  MGS_HIP(ctx, hipGetLastError());
+  const int MAX_ROUNDS = 96, MU_ROUNDS = 24;
+  for (int round = 0; round < MAX_ROUNDS; ++round) {
+    const int hash_only = round >= MU_ROUNDS;
+    const int force = round == MAX_ROUNDS - 1;
+    MGS_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(agg_pick_kernel, g, b, 0, st, n, M->rowptr, M->col, w.as<double>(), state.as<int>(), hash_only, pick.as<int>());
+    hipLaunchKernelGGL(agg_match_kernel, g, b, 0, st, n, pick.as<int>(), state.as<int>(), force, cnt.as<int>());
+    int left = 0;
+    MGS_HIP(ctx, hipMemcpyAsync(&left, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    MGS_HIP(ctx, hipStreamSynchronize(st));
+    if (left == 0) break;
+  }
+  if (Mt) mgs_csr_destroy(Mt);
+  hipLaunchKernelGGL(agg_leader_flag_kernel, dim3(mgs_grid(n + 1, TB)), b, 0, st, n, state.as<int>(), flag.as<int>());
+  MGS_TRY(scan_rec(ctx, flag.as<int>(), flag.as<int>(), (int64_t)n + 1));
+  int nc = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&nc, flag.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+  int *agg = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &agg, (size_t)n));
+  hipLaunchKernelGGL(agg_assign_kernel, g, b, 0, st, n, state.as<int>(), flag.as<int>(), agg);
+  MGS_HIP(ctx, hipGetLastError());
+  MGS_HIP(ctx, hipStreamSynchronize(st));
+  *agg_out = agg; *nc_out = nc;
+  return MGS_OK;
+}
+
+// multiple pairwise aggregation, AGMG.cpp:299-315 / main.cu:95-277
+int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, A->rows == A->cols && A->rows > 0, MGS_ERR_INVALID, "aggregate: square non-empty matrix required");
+  MGS_CHECK(ctx, ktg > 2.0 && npass >= 1, MGS_ERR_INVALID, "aggregate: need ktg > 2 and npass >= 1");
+  const int n = A->rows;
+  int *agg = nullptr; int nc = 0;
+  MGS_TRY(pairwise_pass(A, ktg, 1, &agg, &nc));
+  mgs_xfer *T = nullptr;
+  MGS_TRY(xfer_from_agg(ctx, n, nc, agg, &T));
+  mgs_csr *Abar = nullptr;
+  int rc = k_galerkin_agg(A, T, &Abar);
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); return rc; }
+  for (int s = 2; s <= npass; ++s) {
+    if ((double)Abar->nnz <= (double)A->nnz / tou) break;               // AGMG.cpp:309
+    if (Abar->rows <= 1) break;
+    int *agg2 = nullptr; int nc2 = 0;
+    rc = pairwise_pass(Abar, ktg, 0, &agg2, &nc2);
+    if (rc != MGS_OK) break;
+    // compose fine→pair→pair-of-pairs (AGMG.cpp:247-263) and rebuild member lists
+    int *aggc = nullptr;
+    rc = mgs_dev_alloc(ctx, &aggc, (size_t)n);
+    if (rc != MGS_OK) { hipFree(agg2); break; }
+    hipMemcpyAsync(aggc, T->agg, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
+    hipLaunchKernelGGL(agg_compose_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, aggc, agg2);
+    mgs_xfer *T2 = nullptr, *Tn = nullptr;
+    rc = xfer_from_agg(ctx, Abar->rows, nc2, agg2, &T2);
+    mgs_csr *Anew = nullptr;
+    if (rc == MGS_OK) rc = k_galerkin_agg(Abar, T2, &Anew);          // (P1 P2)ᵀ A (P1 P2) = P2ᵀ A_bar P2
+    if (T2) mgs_xfer_destroy(T2);
+    if (rc == MGS_OK) rc = xfer_from_agg(ctx, n, nc2, aggc, &Tn); else hipFree(aggc);
+    if (rc != MGS_OK) { if (Anew) mgs_csr_destroy(Anew); break; }
+    mgs_xfer_destroy(T); T = Tn;
+    mgs_csr_destroy(Abar); Abar = Anew;
+  }
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); mgs_csr_destroy(Abar); return rc; }
+  *T_out = T; *Ac_out = Abar;
+  return MGS_OK;
+}
