@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — V-cycles/s and fine-level CSR-SpMV HBM GB/s on the synthetic 7-point 3-D Poisson
+problem (BASELINE.json configs[4], grid 512^3), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one application of the V-cycle preconditioner (MultiGridPrecond::solve, reference
+src/common/bicg.cpp:51-61) to a fixed right-hand side that is already resident in HBM.  The
+hierarchy is built on the device (mgs_hier_coarsen) before the timed region.  N>1 shards the
+fine grid by contiguous plane ranges (strong scaling: the 512^3 problem is fixed) and exchanges
+one halo plane per neighbour per SpMV-shaped kernel through torch.distributed (RCCL).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description): value = whole-job
+V-cycles/s; "roofline" = achieved algorithmic HBM GB/s of the fine-level SpMV kernel measured
+live with HIP events on the stream the kernel runs on; "cpu_baseline" = the CPU oracle's V-cycle
+(port of the same cycle) timed on this host on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def spmv_bytes(n, nnz):      # BASELINE.md §2 / SURVEY §8d row d3
+    return 12 * nnz + 20 * n + 4
+
+
+def jacobi_bytes(n, nnz):
+    return 12 * nnz + 36 * n + 4
+
+
+def residual_bytes(n, nnz):
+    return 12 * nnz + 28 * n + 4
+
+
+def cpu_baseline(mg, args):
+    """CPU oracle V-cycle (port of the same cycle, 1 thread) on a bounded sample: a smaller grid
+    with the hierarchy the device built for it, scaled by the row ratio.  Also times the
+    reference's own Eigen SpMV kernel (oracle/_ref/libref_eigen.so) when that .so travelled."""
+    from oracle import oracle_py as orc
+    import scipy.sparse as sps
+    Ns = args.cpu_grid
+    ctx = mg.Context(0)
+    A = ctx.poisson3d(Ns)
+    h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+    As, Ps = [], []
+    for l in range(h.nlev):
+        rp, ci, v = h.level_A(l).download()
+        rows = h.level_shape(l)[0]
+        As.append(orc.Csr.from_arrays(rows, rows, rp, ci, v))
+        if l < h.nlev - 1:
+            T = h.level_P(l); agg = T.agg(); nf, nc = T.shape
+            r = np.nonzero(agg >= 0)[0]
+            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(r.size), (r, agg[r])), shape=(nf, nc))))
+    n = Ns ** 3
+    b = ctx.vec(n).rand(seed=0).numpy()
+    ho = orc.Hier(As[0], Ps, omega=args.omega, nu1=args.nu1, nu2=args.nu2, As=As)
+    ho.vcycle(b)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 6.0:
+        x = ho.vcycle(b); reps += 1
+    t_cycle = (time.perf_counter() - t0) / reps
+    # parity of this very sample against the GPU cycle (cheap, keeps the baseline honest)
+    xg = h.vcycle(ctx.vec(b)).numpy()
+    err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
+    scale = (args.grid / Ns) ** 3
+    out = {"value": 1.0 / (t_cycle * scale), "unit": "V-cycles/s", "cores": 1, "kind": "port",
+           "sample": f"oracle V({args.nu1},{args.nu2}) cycle on a {Ns}^3 grid ({n} rows, {h.nlev} levels built on device), "
+                     f"{reps} cycles of {t_cycle * 1e3:.1f} ms, scaled by the row ratio x{scale:.0f} to {args.grid}^3",
+           "sample_ms_per_cycle": t_cycle * 1e3, "gpu_vs_oracle_rel_err_on_sample": err}
+    # reference's own SpMV kernel (Eigen 3.3.4, 1 thread) on the sample's fine operator
+    so = os.path.join(REPO, "oracle", "_ref", "libref_eigen.so")
+    rp, ci, v = As[0].rowptr, As[0].col, As[0].val
+    nnz = len(ci)
+    xs = np.random.default_rng(0).random(n); y = np.empty(n)
+    if os.path.exists(so):
+        L = C.CDLL(so)
+        L.ref_eigen_spmv.restype = C.c_double
+        L.ref_eigen_spmv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        t = L.ref_eigen_spmv(n, n, nnz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, xs.ctypes.data, y.ctypes.data, 5)
+        out["spmv_eigen_reference_gbps"] = spmv_bytes(n, nnz) / t / 1e9
+        out["spmv_eigen_reference_ms"] = t * 1e3
+    t0 = time.perf_counter()
+    for _ in range(5):
+        As[0].spmv(xs)
+    t = (time.perf_counter() - t0) / 5
+    out["spmv_oracle_port_gbps"] = spmv_bytes(n, nnz) / t / 1e9
+    try:
+        out["host_cpu"] = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        out["host_nproc"] = os.cpu_count()
+    except Exception:  # noqa: BLE001
+        pass
+    del h, A
+    ctx.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=512, help="N of the N^3 7-point Poisson grid (headline: 512)")
+    ap.add_argument("--omega", type=float, default=0.6)
+    ap.add_argument("--nu1", type=int, default=1)
+    ap.add_argument("--nu2", type=int, default=1)
+    ap.add_argument("--ktg", type=float, default=10.0)
+    ap.add_argument("--npass", type=int, default=2)
+    ap.add_argument("--tou", type=float, default=8.0)
+    ap.add_argument("--coarse-rows", type=int, default=1024)
+    ap.add_argument("--cpu-grid", type=int, default=128)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import multigridsolver_amd as mg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        from multigridsolver_amd import dist as mgdist
+        return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes)
+
+    ctx = mg.Context(local_rank)
+    N = args.grid
+    n = N ** 3
+    t0 = time.perf_counter()
+    A = ctx.poisson3d(N)
+    ctx.sync()
+    nnz = A.nnz
+    log(f"generated {N}^3 operator on device: {n} rows, {nnz} nnz in {time.perf_counter() - t0:.2f}s")
+    t0 = time.perf_counter()
+    h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+    ctx.sync()
+    t_setup = time.perf_counter() - t0
+    levels = [h.level_shape(l) for l in range(h.nlev)]
+    log(f"hierarchy built on device in {t_setup:.2f}s: " + " > ".join(f"{r}r/{z}nnz" for r, z in levels))
+
+    b = ctx.vec(n).rand(seed=0)
+    x = ctx.vec(n)
+    # ---- roofline of the dominant kernel: fine-level CSR SpMV (HIP events on the kernel's stream)
+    xs = ctx.vec(n).rand(seed=1)
+    y = ctx.vec(n)
+    dinv = A.diag_inv()
+    A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
+    ms_spmv = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=args.kernel_reps)
+    ms_res = A.time_kernel(mg.OP_RESIDUAL, xs, b=b, out=y, reps=args.kernel_reps)
+    ms_jac = A.time_kernel(mg.OP_JACOBI, xs, b=b, dinv=dinv, out=y, reps=args.kernel_reps)
+    gbps = lambda byts, ms: byts / (ms * 1e-3) / 1e9  # noqa: E731
+    spmv_gbps = gbps(spmv_bytes(n, nnz), ms_spmv)
+    log(f"fine SpMV {ms_spmv:.3f} ms = {spmv_gbps:.0f} GB/s; residual {ms_res:.3f} ms = {gbps(residual_bytes(n, nnz), ms_res):.0f} GB/s; "
+        f"jacobi {ms_jac:.3f} ms = {gbps(jacobi_bytes(n, nnz), ms_jac):.0f} GB/s")
+    del xs, y
+
+    # ---- timed region: W warm-up + exactly K V-cycles
+    for _ in range(args.warmup):
+        h.vcycle(b, x)
+    ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.vcycle(b, x)
+    ctx.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms_step = elapsed / args.steps * 1e3
+    vbytes = h.vcycle_bytes
+    log(f"V-cycle {ms_step:.3f} ms ({args.steps / elapsed:.2f} /s), algorithmic {vbytes / 1e9:.2f} GB/cycle = {vbytes / elapsed * args.steps / 1e9:.0f} GB/s")
+
+    # quality: residual reduction of one cycle and a preconditioned solve to 1e-10 (untimed)
+    r0 = b.nrm2(); r1 = A.residual(x, b).nrm2()
+    xsol = ctx.vec(n)
+    t0 = time.perf_counter()
+    st, it, tol = mg.bicgstab(A, xsol, b, h, 200, 1e-10)
+    t_solve = time.perf_counter() - t0
+    log(f"one cycle: |r|/|b| = {r1 / r0:.3e}; BiCGSTAB+V-cycle to 1e-10: status {st}, {it} iterations, tol {tol:.2e}, {t_solve:.2f}s")
+
+    out = {
+        "metric": "V-cycles/sec + fine-level SpMV HBM GB/s, 512³ 7-pt Poisson, 1/2/4/8 GPU",
+        "value": args.steps / elapsed, "unit": "V-cycles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"poisson3d_{N}^3_7pt (BASELINE.json configs[4]); V({args.nu1},{args.nu2}) damped-Jacobi cycle, omega={args.omega}, "
+                               f"hierarchy built on device by pairwise aggregation ktg={args.ktg} npass={args.npass} tou={args.tou}",
+                   "grid": N, "rows": n, "nnz": nnz, "levels": levels, "parallelism": "1 GPU", "setup_seconds": t_setup},
+        "spmv_hbm_gbps": spmv_gbps,
+        "roofline": {"bound": "hbm", "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": spmv_gbps / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "csr_rowblock_kernel<SPMV> (fine level)", "algorithmic_bytes_per_launch": spmv_bytes(n, nnz),
+                     "ms_per_launch": ms_spmv,
+                     "other_kernels": {"residual": {"ms": ms_res, "gbps": gbps(residual_bytes(n, nnz), ms_res)},
+                                       "jacobi": {"ms": ms_jac, "gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
+                     "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9},
+        "solve_check": {"one_cycle_residual_reduction": r1 / r0, "bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol,
+                        "bicgstab_seconds": t_solve},
+    }
+    del h, A, b, x, xsol, dinv
+    ctx.close()
+    if not args.no_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(mg, args)
+        except Exception as e:  # noqa: BLE001
+            log("cpu_baseline failed:", repr(e))
+            out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -206,6 +206,24 @@ int mgs_halo_pack(mgs_ctx *ctx, const mgs_vec *x, const int *send_idx_dev, int64
  * n_halo entries and the callee must fill x_dev[n_loc..] on ctx's stream.             */
 typedef int (*mgs_halo_fn)(void *user, int level, void *x_dev);
 int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user);
+/* Building blocks of a row-sharded hierarchy (one process per GPU; orchestration in
+ * multigridsolver_amd/dist.py).  mgs_aggregate_shard: pairwise aggregation of the OWNED
+ * rows only (aggregates never straddle a shard; couplings to halo columns enter s_i and the
+ * G0 test as symmetric).  The caller then learns the remote aggregate of every halo slot from
+ * its peers and passes the coarse column of each halo slot (host array, n_halo ints, values
+ * in [n_coarse, n_coarse+n_halo_coarse) or −1) to mgs_galerkin_shard, which returns the coarse
+ * shard (n_coarse rows, n_coarse+n_halo_coarse local columns).  mgs_hier_push_level appends
+ * the pair to a hierarchy and takes ownership of both.                                  */
+int mgs_aggregate_shard(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T);
+int mgs_galerkin_shard(const mgs_csr *A, const mgs_xfer *T, const int *halo_coarse_col,
+                       int n_halo_coarse, mgs_csr **Ac);
+int mgs_hier_push_level(mgs_hier *h, mgs_xfer *T, mgs_csr *Ac);
+/* aggregation transfer from a host array of aggregate ids (−1 = none)                   */
+int mgs_xfer_from_agg(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg, mgs_xfer **out);
+/* coarsest-level solver callback (x_dev = solve(b_dev), both of the coarsest level's owned
+ * size) — used for the replicated tail of a sharded hierarchy; replaces the dense inverse. */
+typedef int (*mgs_coarse_fn)(void *user, const void *b_dev, void *x_dev);
+int mgs_hier_set_coarse_solver(mgs_hier *h, mgs_coarse_fn fn, void *user);
 /* reduction callback for dot products of sharded vectors (sum over ranks)             */
 typedef int (*mgs_allreduce_fn)(void *user, double *host_scalars, int count);
 int mgs_ctx_set_allreduce(mgs_ctx *ctx, mgs_allreduce_fn fn, void *user);

@@ -13,6 +13,7 @@ c_int_p = C.POINTER(C.c_int)
 c_dbl_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+COARSE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_dbl_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol declared in include/mgs.h
@@ -75,6 +76,11 @@ PROTOTYPES = {
     "mgs_bicgstab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_dbl_p, c_int_p]),
     "mgs_halo_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgs_hier_set_halo_exchange": (C.c_int, [C.c_void_p, HALO_FN, C.c_void_p]),
+    "mgs_aggregate_shard": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
+    "mgs_galerkin_shard": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mgs_hier_push_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_xfer_from_agg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(C.c_void_p)]),
+    "mgs_hier_set_coarse_solver": (C.c_int, [C.c_void_p, COARSE_FN, C.c_void_p]),
     "mgs_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mgs_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),
     "mgs_time_vcycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),

@@ -346,6 +346,36 @@ int mgs_hier_push_P(mgs_hier *h, const mgs_csr *P) {
   return push_level(h, T, Ac);
 }
 
+int mgs_aggregate_shard(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T) {
+  mgs_csr *Ac = nullptr;
+  MGS_TRY(k_pairwise_aggregate(A, ktg, npass, tou, T, &Ac));
+  if (Ac) mgs_csr_destroy(Ac);
+  return MGS_OK;
+}
+int mgs_galerkin_shard(const mgs_csr *A, const mgs_xfer *T, const int *halo_coarse_col, int n_halo_coarse, mgs_csr **Ac) {
+  mgs_ctx *ctx = A->ctx;
+  const int n_halo = A->cols - A->rows;
+  MGS_CHECK(ctx, n_halo >= 0 && (n_halo == 0 || halo_coarse_col), MGS_ERR_INVALID, "mgs_galerkin_shard: halo map missing");
+  if (n_halo == 0) return k_galerkin_agg(A, T, Ac);
+  for (int k = 0; k < n_halo; ++k)
+    MGS_CHECK(ctx, halo_coarse_col[k] == -1 || (halo_coarse_col[k] >= T->n_coarse && halo_coarse_col[k] < T->n_coarse + n_halo_coarse), MGS_ERR_INVALID,
+              "mgs_galerkin_shard: halo slot %d maps to coarse column %d outside [%d,%d)", k, halo_coarse_col[k], T->n_coarse, T->n_coarse + n_halo_coarse);
+  int *d = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &d, (size_t)n_halo));
+  MGS_HIP(ctx, hipMemcpyAsync(d, halo_coarse_col, sizeof(int) * (size_t)n_halo, hipMemcpyHostToDevice, ctx->stream));
+  int rc = k_galerkin_agg_ext(A, T, d, n_halo_coarse, Ac);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  return rc;
+}
+int mgs_hier_push_level(mgs_hier *h, mgs_xfer *T, mgs_csr *Ac) {
+  mgs_ctx *ctx = h->ctx;
+  MGS_CHECK(ctx, T && Ac && T->n_fine == h->lev.back().A->rows && T->n_coarse == Ac->rows && Ac->rows <= Ac->cols, MGS_ERR_INVALID, "mgs_hier_push_level: shape mismatch");
+  return push_level(h, T, Ac);
+}
+int mgs_xfer_from_agg(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg, mgs_xfer **out) { return k_xfer_from_agg_host(ctx, n_fine, n_coarse, agg, out); }
+int mgs_hier_set_coarse_solver(mgs_hier *h, mgs_coarse_fn fn, void *user) { h->coarse = fn; h->coarse_user = user; drop_graph(h); if (fn) h->finalized = true; return MGS_OK; }
+
 int mgs_hier_coarsen(mgs_hier *h, double ktg, int npass, double tou, int coarse_rows, int max_levels) {
   mgs_ctx *ctx = h->ctx;
   while ((int)h->lev.size() < max_levels && h->lev.back().A->rows > coarse_rows) {
@@ -375,17 +405,20 @@ int mgs_hier_finalize(mgs_hier *h) {
 }
 
 int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
-  // per level  (ν1+ν2)·Jacobi + residual + restriction + prolongation (zero-guess
-  // shortcuts on the first pre-sweep not credited), coarsest: dense inverse apply.
+  // algorithmic bytes of the kernels one zero-guess cycle actually launches.
+  // Level 0 starts from x = 0 and so does every coarse level: the first pre-sweep is the
+  // 24n-byte (ωD⁻¹)b kernel, not a Jacobi pass.
   int64_t tot = 0;
   const int L = (int)h->lev.size();
   for (int l = 0; l < L - 1; ++l) {
     const mgs_level &lv = h->lev[l];
     int64_t n = lv.A->rows, nnz = lv.A->nnz, nc = h->lev[l + 1].A->rows, nnzP = lv.T ? lv.T->nnz : 0;
-    tot += (int64_t)(h->nu1 + h->nu2) * (12 * nnz + 36 * n + 4);
-    tot += 12 * nnz + 28 * n + 4;
-    tot += 4 * (nc + 1) + 12 * nnzP + 8 * nc;
-    tot += 20 * n + 8 * nc;
+    const int64_t jac = 12 * nnz + 36 * n + 4, res = 12 * nnz + 28 * n + 4;
+    if (h->nu1 > 0) tot += 24 * n + (int64_t)(h->nu1 - 1) * jac + res;   // shortcut + sweeps + residual
+    // ν1 = 0: r = b, no residual pass
+    tot += 4 * (nc + 1) + 12 * nnzP + 8 * nc;                              // restriction
+    tot += (h->nu1 > 0 ? 20 * n : 12 * n) + 8 * nc;                        // prolong-add / prolong
+    tot += (int64_t)h->nu2 * jac;
   }
   tot += (int64_t)h->nc * h->nc * 8 + 16 * (int64_t)h->nc;
   return tot;
@@ -410,7 +443,10 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   mgs_ctx *ctx = h->ctx;
   mgs_level &L = h->lev[l];
   const int n = L.n;
-  if (l == (int)h->lev.size() - 1) return k_dense_gemv(ctx, h->nc, h->inv, b, x);
+  if (l == (int)h->lev.size() - 1) {
+    if (h->coarse) { int rc = h->coarse(h->coarse_user, b, x); return rc ? mgs_fail(ctx, MGS_ERR_STATE, "coarse solver callback failed (%d)", rc) : MGS_OK; }
+    return k_dense_gemv(ctx, h->nc, h->inv, b, x);
+  }
   mgs_level &C = h->lev[l + 1];
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
   int swaps = h->nu2 + (zero_guess ? (h->nu1 > 0 ? h->nu1 - 1 : 0) : h->nu1);
@@ -456,12 +492,12 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   mgs_level &L0 = h->lev[0];
   MGS_CHECK(ctx, b->n >= L0.n && x->n >= L0.n, MGS_ERR_INVALID, "mgs_vcycle: vectors shorter than the operator (%d rows)", L0.n);
   MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
-  if (h->lev.size() == 1) return k_dense_gemv(ctx, h->nc, h->inv, b->d, x->d);
+  if (h->lev.size() == 1) return cycle_level(h, 0, b->d, x->d, true);
   // sharded level 0 needs halo room behind the owned entries: work in the level's own buffer
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
-  const bool use_graph = ctx->opt_graph && !h->halo;
+  const bool use_graph = ctx->opt_graph && !h->halo && !h->coarse;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {

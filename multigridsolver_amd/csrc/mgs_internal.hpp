@@ -85,6 +85,8 @@ struct mgs_hier {
   double *inv = nullptr;  // nc*nc dense inverse (row-major)
   mgs_halo_fn halo = nullptr;
   void *halo_user = nullptr;
+  mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
+  void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle
   hipGraphExec_t graph = nullptr;
   const double *graph_b = nullptr;
@@ -140,6 +142,8 @@ int k_transpose(const mgs_csr *A, mgs_csr **out);
 // (setup_agmg.hip)
 int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host);
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
+int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out);
+int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_host, mgs_xfer **out);
 int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
 int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out);
 

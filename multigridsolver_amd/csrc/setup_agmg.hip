@@ -136,7 +136,7 @@ __global__ void galerkin_ub_kernel(int nc, const int *__restrict__ cptr, const i
 }
 // one lane per coarse row: gather (agg(col), val) of all member rows, insertion-sort by
 // coarse column (stable: fine order i↑, j↑ inside a key), then reduce equal keys in place.
-__global__ void galerkin_fill_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg,
+__global__ void galerkin_fill_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg /*column map, size = cols of A*/,
                                      const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
                                      const int *__restrict__ offs, int *__restrict__ scol, double *__restrict__ sval, int *__restrict__ uniq) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,7 +188,7 @@ __global__ void pattern_asym_kernel(int n, const int *__restrict__ rowptr, const
   int bad = 0;
   for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
     int j = col[k];
-    if (j == i) continue;
+    if (j == i || j >= n) continue;               // halo columns (row shards) are not owned rows
     int lo = rowptr[j], hi = rowptr[j + 1] - 1; bool found = false;
     while (lo <= hi) { int mid = (lo + hi) >> 1; int c = col[mid]; if (c == i) { found = true; break; } if (c < i) lo = mid + 1; else hi = mid - 1; }
     if (!found) ++bad;
@@ -208,7 +208,9 @@ __global__ void agg_node_stats_kernel(int n, const int *__restrict__ rowptr, con
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
       int j = col[k]; double aij = val[k];
       if (j == i) { aii = aij; continue; }
-      double aji = csr_lookup(rowptr, col, val, j, i);
+      // off-shard neighbour (halo column of a row shard): its row lives on another GPU; the
+      // coupling is taken as symmetric, a_ji := a_ij
+      double aji = j < n ? csr_lookup(rowptr, col, val, j, i) : aij;
       ssum += (aij + aji) / 2; asum += fabs((aij + aji) / 2);
     }
   } else {
@@ -219,6 +221,7 @@ __global__ void agg_node_stats_kernel(int n, const int *__restrict__ rowptr, con
       double aij = 0.0, aji = 0.0;
       if (jr == j) aij = val[r++];
       if (jc == j) aji = tval[c++];
+      if (j >= n) aji = aij;                        // halo column: symmetric coupling assumed
       if (j == i) { aii = aij; continue; }
       ssum += (aij + aji) / 2; asum += fabs((aij + aji) / 2);
     }
@@ -240,7 +243,7 @@ __global__ void agg_edge_weight_kernel(int n, const int *__restrict__ rowptr, co
   for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
     int j = col[k]; double aij = val[k];
     double wk = INFINITY;
-    if (j != i && aij != 0.0 && !gi && state[j] != -2) {
+    if (j != i && j < n && aij != 0.0 && !gi && state[j] != -2) {
       double ajj = diag[j], sj = s[j];
       if (aii - si + ajj - sj >= 0) {
         double aji = csr_lookup(rowptr, col, val, j, i);
@@ -360,6 +363,16 @@ int xfer_from_agg(mgs_ctx *ctx, int n, int nc, int *agg_owned, mgs_xfer **out) {
 
 }  // namespace
 
+int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_host, mgs_xfer **out) {
+  int *agg = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &agg, (size_t)n_fine));
+  for (int i = 0; i < n_fine; ++i)
+    if (agg_host[i] < -1 || agg_host[i] >= n_coarse) { hipFree(agg); return mgs_fail(ctx, MGS_ERR_INVALID, "aggregate id %d of row %d outside [-1,%d)", agg_host[i], i, n_coarse); }
+  MGS_HIP(ctx, hipMemcpyAsync(agg, agg_host, sizeof(int) * (size_t)n_fine, hipMemcpyHostToDevice, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return xfer_from_agg(ctx, n_fine, n_coarse, agg, out);
+}
+
 int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host) {
   MGS_TRY(scan_rec(ctx, in, out, n));
   if (total_host) {
@@ -419,27 +432,27 @@ int k_xfer_from_csr(const mgs_csr *P, mgs_xfer **out) {
   return MGS_OK;
 }
 
-int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+// A_c[I, colmap(j)] += a_ij for i in members(I).  colmap has one entry per column of A (owned
+// rows first, then halo slots for row shards); ncols_out = number of coarse columns.
+static int galerkin_core(const mgs_csr *A, int nc, const int *cptr, const int *members, const int *colmap, int ncols_out, mgs_csr **out) {
   mgs_ctx *ctx = A->ctx;
-  MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows == A->cols, MGS_ERR_INVALID, "galerkin: shape mismatch");
-  const int nc = T->n_coarse;
   DevBuf ub, uniq, scol, sval;
   MGS_TRY(dalloc<int>(ctx, ub, (size_t)nc + 1));
   MGS_TRY(dalloc<int>(ctx, uniq, (size_t)nc + 1));
-  hipLaunchKernelGGL(galerkin_ub_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, T->cptr, T->members, A->rowptr, ub.as<int>());
+  hipLaunchKernelGGL(galerkin_ub_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, A->rowptr, ub.as<int>());
   MGS_TRY(scan_rec(ctx, ub.as<int>(), ub.as<int>(), (int64_t)nc + 1));
   int tot = 0;
   MGS_HIP(ctx, hipMemcpyAsync(&tot, ub.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_TRY(dalloc<int>(ctx, scol, (size_t)tot));
   MGS_TRY(dalloc<double>(ctx, sval, (size_t)tot));
-  hipLaunchKernelGGL(galerkin_fill_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, T->cptr, T->members, T->agg, A->rowptr, A->col, A->val, ub.as<int>(), scol.as<int>(), sval.as<double>(), uniq.as<int>());
+  hipLaunchKernelGGL(galerkin_fill_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, colmap, A->rowptr, A->col, A->val, ub.as<int>(), scol.as<int>(), sval.as<double>(), uniq.as<int>());
   MGS_TRY(scan_rec(ctx, uniq.as<int>(), uniq.as<int>(), (int64_t)nc + 1));
   int nnzc = 0;
   MGS_HIP(ctx, hipMemcpyAsync(&nnzc, uniq.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   mgs_csr *C = nullptr;
-  MGS_TRY(mgs_csr_alloc(ctx, nc, nc, nnzc, &C));
+  MGS_TRY(mgs_csr_alloc(ctx, nc, ncols_out, nnzc, &C));
   MGS_HIP(ctx, hipMemcpyAsync(C->rowptr, uniq.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, ctx->stream));
   if (nc) hipLaunchKernelGGL(galerkin_copy_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, ub.as<int>(), C->rowptr, scol.as<int>(), sval.as<double>(), C->col, C->val);
   MGS_HIP(ctx, hipGetLastError());
@@ -448,6 +461,26 @@ int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
   *out = C;
   return MGS_OK;
 }
+
+__global__ void colmap_ext_kernel(int n, int n_ext, int nc, const int *__restrict__ agg, const int *__restrict__ halo_map, int *__restrict__ colmap) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_ext) return;
+  colmap[j] = j < n ? agg[j] : (halo_map ? halo_map[j - n] : nc + (j - n));   // identity on halo slots when no map is given
+}
+
+// square A: A_c = PᵀAP.  Row shard (cols > rows): halo_map gives the coarse column of every halo
+// slot (device array of cols−rows ints, −1 = not aggregated), n_halo_c coarse halo slots.
+int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows <= A->cols, MGS_ERR_INVALID, "galerkin: shape mismatch");
+  if (A->rows == A->cols) return galerkin_core(A, T->n_coarse, T->cptr, T->members, T->agg, T->n_coarse, out);
+  DevBuf cm;
+  MGS_TRY(dalloc<int>(ctx, cm, (size_t)A->cols));
+  const int n_halo = A->cols - A->rows;
+  hipLaunchKernelGGL(colmap_ext_kernel, dim3(mgs_grid(A->cols, TB)), dim3(TB), 0, ctx->stream, A->rows, A->cols, T->n_coarse, T->agg, halo_map_dev, cm.as<int>());
+  return galerkin_core(A, T->n_coarse, T->cptr, T->members, cm.as<int>(), T->n_coarse + (halo_map_dev ? n_halo_c : n_halo), out);
+}
+int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) { return k_galerkin_agg_ext(A, T, nullptr, 0, out); }
 
 // general P (not an aggregation): host Gustavson product, as the reference does with Eigen on
 // the CPU at setup (bicg.cpp:33).  Setup only — never on the solve path.
@@ -535,7 +568,7 @@ static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, int **agg
 // multiple pairwise aggregation, AGMG.cpp:299-315 / main.cu:95-277
 int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out) {
   mgs_ctx *ctx = A->ctx;
-  MGS_CHECK(ctx, A->rows == A->cols && A->rows > 0, MGS_ERR_INVALID, "aggregate: square non-empty matrix required");
+  MGS_CHECK(ctx, A->rows <= A->cols && A->rows > 0, MGS_ERR_INVALID, "aggregate: need a non-empty operator with rows <= cols");
   MGS_CHECK(ctx, ktg > 2.0 && npass >= 1, MGS_ERR_INVALID, "aggregate: need ktg > 2 and npass >= 1");
   const int n = A->rows;
   int *agg = nullptr; int nc = 0;
@@ -548,6 +581,7 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
   for (int s = 2; s <= npass; ++s) {
     if ((double)Abar->nnz <= (double)A->nnz / tou) break;               // AGMG.cpp:309
     if (Abar->rows <= 1) break;
+    const int n_halo = A->cols - A->rows;                               // row shard: halo slots stay unaggregated here
     int *agg2 = nullptr; int nc2 = 0;
     rc = pairwise_pass(Abar, ktg, 0, &agg2, &nc2);
     if (rc != MGS_OK) break;
@@ -560,6 +594,7 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     mgs_xfer *T2 = nullptr, *Tn = nullptr;
     rc = xfer_from_agg(ctx, Abar->rows, nc2, agg2, &T2);
     mgs_csr *Anew = nullptr;
+    (void)n_halo;
     if (rc == MGS_OK) rc = k_galerkin_agg(Abar, T2, &Anew);          // (P1 P2)ᵀ A (P1 P2) = P2ᵀ A_bar P2
     if (T2) mgs_xfer_destroy(T2);
     if (rc == MGS_OK) rc = xfer_from_agg(ctx, n, nc2, aggc, &Tn); else hipFree(aggc);
@@ -568,6 +603,8 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     mgs_csr_destroy(Abar); Abar = Anew;
   }
   if (rc != MGS_OK) { mgs_xfer_destroy(T); mgs_csr_destroy(Abar); return rc; }
-  *T_out = T; *Ac_out = Abar;
+  *T_out = T;
+  if (A->rows == A->cols) *Ac_out = Abar;
+  else { mgs_csr_destroy(Abar); *Ac_out = nullptr; }   // shard: the caller resolves remote aggregates, then k_galerkin_agg_ext
   return MGS_OK;
 }

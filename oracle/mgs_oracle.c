@@ -682,7 +682,7 @@ static int agmg_further(const orc_csr *A, double ktg, const orc_csr *Pbar_t,
 /* AGMG.cpp:299-315 */
 int orc_agmg(const orc_csr *A, double ktg, int npass, double tou, int max_restriction, orc_csr *P) {
   int rc = agmg_initial(A, ktg, P);
-  if (rc) return rc;
+  if (rc && rc != -2) return rc;   /* -2: P is complete but the reference's assert(i<j) would fire */
   for (int s = 2; s <= npass; s++) {
     orc_csr Pt, Abar, Pn;
     orc_transpose(P, &Pt);
@@ -695,5 +695,5 @@ int orc_agmg(const orc_csr *A, double ktg, int npass, double tou, int max_restri
     orc_csr_free(&Pt); orc_csr_free(&Abar);
     if (stop) break;
   }
-  return 0;
+  return rc;
 }

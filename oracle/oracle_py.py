@@ -178,10 +178,12 @@ class Csr:
         dinv = np.ascontiguousarray(dinv, dtype=np.float64)
         out = np.empty(self.c.rows); lib().orc_jacobi(self.ref(), _dp(dinv), omega, _dp(b), _dp(x), _dp(out)); return out
 
-    def agmg(self, ktg=10.0, npass=2, tou=8.0, max_restriction=0):
+    def agmg(self, ktg=10.0, npass=2, tou=8.0, max_restriction=0, strict=True):
+        """strict=False accepts rc=-2: P is complete, but the reference itself would have stopped
+        on its assert(i < j) (AGMG.cpp:156) for this numbering."""
         m = Csr()
         rc = lib().orc_agmg(self.ref(), ktg, npass, tou, max_restriction, m.ref())
-        if rc:
+        if rc and not (rc == -2 and not strict):
             raise RuntimeError(f"orc_agmg -> {rc}")
         m._owned = True
         return m

@@ -1,0 +1,101 @@
+"""Worker of tests/test_gpu_dist.py: launched with torch.distributed.run, 2 ranks sharing GPU 0
+(backend gloo, halo buffers staged through the host — the transport is the only part that
+differs from the RCCL run).  Builds the sharded hierarchy of an N^3 Poisson operator through the
+C-ABI, runs the C++ V-cycle with the exchange callbacks and compares with the CPU oracle's
+V-cycle on the hierarchy assembled globally.  Prints 'DIST_OK' on rank 0."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    import scipy.sparse as sps
+    import torch
+    import torch.distributed as dist
+    import multigridsolver_amd as mg
+    from multigridsolver_amd import dist as mgd
+    from oracle import oracle_py as orc
+
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    tail_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+    ctx = mg.Context(0, stream.cuda_stream)
+    comm = mgd.Comm()
+    lo, hi = mgd.plane_range(N, world, rank)
+    A = ctx.poisson3d(N, lo, hi, local_cols=True)
+    n_loc, n_ext = A.shape
+    sh = mgd.ShardedHierarchy(ctx, A, mgd.poisson_plane_plan(N, world, rank), 0.6, 1, 1, comm)
+    sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100)
+    assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
+    n2 = N * N
+    bg = orc.rand_rhs(N ** 3)
+    b = ctx.vec(bg[lo * n2: hi * n2]); x = ctx.vec(n_ext)
+    sh.vcycle(b, x)
+    x_loc = x.numpy(n_loc)
+    # sharded SpMV with halo exchange == global SpMV
+    xs = ctx.vec(np.concatenate([bg[lo * n2: hi * n2], np.zeros(n_ext - n_loc)])); y = ctx.vec(n_loc)
+    sh.spmv(xs, y)
+    assert np.array_equal(y.numpy(), orc.poisson3d(N).spmv(bg)[lo * n2: hi * n2])
+
+    # ---- assemble the hierarchy globally
+    As, Ps = [], []
+    offs_prev = None
+    for l, plan in enumerate(sh.plans):
+        nl = comm.allgather_ints(plan.n_loc); offs = np.concatenate([[0], np.cumsum(nl)]).astype(np.int64)
+        rp, ci, v = sh.h.level_A(l).download()
+        mine = mgd.shard_to_global(plan, rp, ci, v, offs, rank)
+        parts = [None] * world
+        agg = sh.h.level_P(l).agg() if l < len(sh.plans) - 1 else None
+        dist.all_gather_object(parts, (mine.indptr, mine.indices, mine.data, agg))
+        Ag = sps.vstack([sps.csr_matrix((d, i, p), shape=(len(p) - 1, int(offs[-1]))) for (p, i, d, _) in parts]).tocsr()
+        As.append(Ag)
+        if agg is not None:
+            ncs = comm.allgather_ints(sh.plans[l + 1].n_loc); offs_c = np.concatenate([[0], np.cumsum(ncs)])
+            gagg = np.concatenate([np.where(a >= 0, a + offs_c[r], -1) for r, (_, _, _, a) in enumerate(parts)])
+            rows = np.nonzero(gagg >= 0)[0]
+            Ps.append(sps.csr_matrix((np.ones(rows.size), (rows, gagg[rows])), shape=(int(offs[-1]), int(offs_c[-1]))))
+    for l in range(sh.tail.nlev):
+        if l > 0:
+            rp, ci, v = sh.tail.level_A(l).download(); r = sh.tail.level_shape(l)[0]
+            As.append(sps.csr_matrix((v, ci, rp), shape=(r, r)))
+        if l < sh.tail.nlev - 1:
+            T = sh.tail.level_P(l); a = T.agg(); nf, nc = T.shape
+            rows = np.nonzero(a >= 0)[0]
+            Ps.append(sps.csr_matrix((np.ones(rows.size), (rows, a[rows])), shape=(nf, nc)))
+    # level-0 assembled operator must be the global Poisson matrix
+    assert abs(As[0] - orc.poisson3d(N).to_scipy()).max() == 0
+    # every coarse operator must be the Galerkin product of the level above (oracle)
+    Ao = [orc.Csr.from_scipy(a) for a in As]; Po = [orc.Csr.from_scipy(p) for p in Ps]
+    for l in range(len(Ps)):
+        ref = Ao[l].galerkin(Po[l]).to_scipy()
+        assert abs(ref - As[l + 1]).max() <= 1e-12 * abs(ref).max(), l
+    ho = orc.Hier(Ao[0], Po, omega=0.6, nu1=1, nu2=1, As=Ao)
+    xr = ho.vcycle(bg)
+    err = np.linalg.norm(x_loc - xr[lo * n2: hi * n2]) / np.linalg.norm(xr[lo * n2: hi * n2])
+    assert err <= 1e-10, err
+    # preconditioned solve across shards (dots all-reduced), true residual checked globally
+    xsol = ctx.vec(n_ext)
+    st, it, tol = sh.bicgstab(xsol, b, 300, 1e-10)
+    assert st == 0 and tol < 1e-10, (st, it, tol)
+    parts = [None] * world
+    dist.all_gather_object(parts, xsol.numpy(n_loc))
+    xg = np.concatenate(parts)
+    res = np.linalg.norm(orc.poisson3d(N).residual(xg, bg)) / np.linalg.norm(bg)
+    assert res <= 1.5e-10, res
+    dist.barrier()
+    if rank == 0:
+        print(f"DIST_OK world={world} N={N} sharded_levels={len(sh.plans)} total_levels={sh.nlev} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
+    del sh, b, x, xs, y, xsol, A
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
