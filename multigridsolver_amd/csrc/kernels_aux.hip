@@ -228,13 +228,19 @@ __global__ void poisson3d_kernel(int N, int plane_lo, int64_t n_loc, int local_c
     if (l >= n_loc) return (int)(hi_halo + (l - n_loc));
     return (int)l;
   };
-  if (i > 0)     { col[p] = cidx(e - N2); val[p++] = -1.0; }
+  // rows stay sorted by (local) column: with local numbering the halo columns are the largest,
+  // so an off-shard e−N² / e+N² neighbour moves to the end of the row
+  const bool lo_is_halo = local_cols && i > 0 && i == plane_lo;
+  const bool hi_is_halo = local_cols && i < N - 1 && (e + N2 - e0) >= n_loc;
+  if (i > 0 && !lo_is_halo)     { col[p] = cidx(e - N2); val[p++] = -1.0; }
   if (j > 0)     { col[p] = cidx(e - N);  val[p++] = -1.0; }
   if (k > 0)     { col[p] = cidx(e - 1);  val[p++] = -1.0; }
   col[p] = cidx(e); val[p++] = 6.0;
   if (k < N - 1) { col[p] = cidx(e + 1);  val[p++] = -1.0; }
   if (j < N - 1) { col[p] = cidx(e + N);  val[p++] = -1.0; }
-  if (i < N - 1) { col[p] = cidx(e + N2); val[p++] = -1.0; }
+  if (i < N - 1 && !hi_is_halo) { col[p] = cidx(e + N2); val[p++] = -1.0; }
+  if (lo_is_halo) { col[p] = cidx(e - N2); val[p++] = -1.0; }
+  if (hi_is_halo) { col[p] = cidx(e + N2); val[p++] = -1.0; }
 }
 // 2-D 5-point, exactly reference src/common/poisson.cpp:9-37.
 __global__ void poisson2d_kernel(int n, int *__restrict__ rowptr, int *__restrict__ col, double *__restrict__ val) {

@@ -166,14 +166,15 @@ class Comm:
             d.all_to_all_single(r, s, recv_counts, send_counts)
             recv.copy_(r)
 
-    def allgather_padded(self, out2d, send_padded):
+    def allgather_padded(self, out_flat, send_padded):
+        """out_flat: world*len(send_padded) entries, rank-major"""
         d = self.dist
         if self.nccl or self.device.type == "cpu":
-            d.all_gather_into_tensor(out2d, send_padded)
+            d.all_gather_into_tensor(out_flat, send_padded)
         else:
-            r = self.torch.empty(out2d.shape, dtype=out2d.dtype)
+            r = self.torch.empty(out_flat.numel(), dtype=out_flat.dtype)
             d.all_gather_into_tensor(r, send_padded.cpu())
-            out2d.copy_(r)
+            out_flat.copy_(r)
 
 
 class _DevPtr:
@@ -195,7 +196,7 @@ class ShardedHierarchy:
         self.h = core.Hierarchy(A_local, omega, nu1, nu2)
         self.smoother = (omega, nu1, nu2)
         self.tail = None
-        self._views, self._bufs, self._keep = {}, {}, []
+        self._views, self._bufs, self._keep, self._xc = {}, {}, [], {}
         self.n_exchanges = 0
 
     # ---- device helpers
@@ -215,16 +216,24 @@ class ShardedHierarchy:
         self._bufs[level] = t.empty(max(len(idx), 1), dtype=t.float64, device=self.comm.device)
 
     def _exchange(self, level, x_ptr):
-        plan = self.plans[level]
-        ns, nr = sum(plan.send_counts), plan.n_halo
+        """halo of x on `level`: pack kernel (gather of the owned rows peers need) on the context's
+        stream, then one all_to_all straight into x's halo slots.  Everything per (level, pointer)
+        is cached: the hot loop does two ctypes calls and one collective."""
+        key = (level, x_ptr)
+        c = self._xc.get(key)
+        if c is None:
+            plan = self.plans[level]
+            ns, nr = sum(plan.send_counts), plan.n_halo
+            c = (ns, nr, core.Vec.wrap(self.ctx, x_ptr, plan.n_loc) if ns else None,
+                 C.c_void_p(plan.dev_send_idx.data_ptr()), C.c_void_p(self._bufs[level].data_ptr()),
+                 self._view(x_ptr + 8 * plan.n_loc, max(nr, 1))[:nr], self._bufs[level][:ns], plan.recv_counts, plan.send_counts)
+            self._xc[key] = c
+        ns, nr, xv, idx_p, buf_p, recv, send, rcnt, scnt = c
         if ns == 0 and nr == 0:
             return
-        buf = self._bufs[level]
         if ns:
-            xv = core.Vec.wrap(self.ctx, x_ptr, plan.n_loc)
-            check(lib().mgs_halo_pack(self.ctx.h, xv.h, C.c_void_p(plan.dev_send_idx.data_ptr()), ns, C.c_void_p(buf.data_ptr())), self.ctx.h)
-        recv = self._view(x_ptr + 8 * plan.n_loc, max(nr, 1))[:nr]
-        self.comm.a2a_f64(recv, buf[:ns], plan.recv_counts, plan.send_counts)
+            check(lib().mgs_halo_pack(self.ctx.h, xv.h, idx_p, ns, buf_p), self.ctx.h)
+        self.comm.a2a_f64(recv, send, rcnt, scnt)
         self.n_exchanges += 1
 
     # ---- setup
@@ -294,7 +303,7 @@ class ShardedHierarchy:
         def coarse(_u, b_ptr, x_ptr):
             try:
                 self._tb_send[:n_loc].copy_(self._view(b_ptr, n_loc))
-                comm.allgather_padded(self._tb_all.view(comm.world, maxn), self._tb_send)
+                comm.allgather_padded(self._tb_all, self._tb_send)
                 t.index_select(self._tb_all, 0, self._tb_idx, out=self._tb_b)
                 self.tail.vcycle(self._tb_bv, self._tb_xv, True)
                 self._view(x_ptr, n_loc).copy_(self._tb_x[o:o + n_loc])

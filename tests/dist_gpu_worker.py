@@ -42,7 +42,8 @@ def main():
     # sharded SpMV with halo exchange == global SpMV
     xs = ctx.vec(np.concatenate([bg[lo * n2: hi * n2], np.zeros(n_ext - n_loc)])); y = ctx.vec(n_loc)
     sh.spmv(xs, y)
-    assert np.array_equal(y.numpy(), orc.poisson3d(N).spmv(bg)[lo * n2: hi * n2])
+    yr = orc.poisson3d(N).spmv(bg)[lo * n2: hi * n2]   # halo terms are summed last in a shard row
+    assert np.linalg.norm(y.numpy() - yr) <= 1e-15 * np.linalg.norm(yr)
 
     # ---- assemble the hierarchy globally
     As, Ps = [], []

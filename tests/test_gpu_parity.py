@@ -183,7 +183,8 @@ def test_generators_match_oracle(ctx, mg, orc):
     assert L.shape == (nloc, nloc + 2 * N2)
     g = sub.indices.astype(np.int64) - 2 * N2
     want = np.where(g < 0, nloc + g + N2, np.where(g >= nloc, nloc + N2 + (g - nloc), g))
-    assert np.array_equal(ci, want)
+    ref = sps.csr_matrix((sub.data, want, sub.indptr), shape=L.shape); ref.sort_indices()   # rows sorted by local column
+    assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(v, ref.data)
 
 
 def test_blas1(ctx, mg, orc):
