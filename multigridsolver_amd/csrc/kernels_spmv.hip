@@ -6,16 +6,17 @@
 //
 // Design: AMG operators of PDE problems have 3..30 entries per row, so a
 // wavefront-per-row kernel would idle ≥57 of 64 lanes.  One 256-thread workgroup owns 256
-// consecutive rows ("row block").  Phase 1 streams the block's contiguous slice of
-// val/col_idx with fully coalesced, non-temporal loads (every lane busy, one entry per
-// lane per step), gathers x[col] through L1/L2 and parks the products in LDS.  Phase 2:
-// lane t adds up row t's products from LDS sequentially in ascending column order — the
-// same order as Eigen's scalar loop (lib/Eigen/src/SparseCore/SparseDenseProduct.h:64-70),
-// which makes the result bit-identical to the CPU path — and applies the fused epilogue.
-// Row blocks whose slice does not fit the LDS budget (long rows) fall back, per block, to
-// a sub-wavefront-per-row reduction with shuffles.  The workgroup→row-block map is
-// XCD-contiguous: the 8 XCDs each sweep one eighth of the rows, so the x planes a block
-// re-reads (e±N, e±N² for the 7-point stencil) stay in that XCD's 4 MiB L2.
+// consecutive rows ("row block") and stages the block's contiguous slice of val/col_idx in
+// LDS with fully coalesced, non-temporal 16-/8-byte loads (every lane busy).  Then lane t walks
+// row t: the 64 lanes of a wave gather x[col] for 64 consecutive rows at once — contiguous
+// runs of x for stencil-like operators — and add the products sequentially in ascending column
+// order, the same order as Eigen's scalar loop
+// (lib/Eigen/src/SparseCore/SparseDenseProduct.h:64-70), so the result is bit-identical to the
+// CPU path; the epilogue (residual / damped Jacobi) is fused.  Row blocks whose slice does not
+// fit the LDS budget (long rows) fall back, per block, to a sub-wavefront-per-row reduction with
+// shuffles.  The workgroup→row-block map is XCD-contiguous (each of the 8 XCDs sweeps one eighth
+// of the rows so re-read x planes stay in that XCD's 4 MiB L2), optionally strip-major.
+// The earlier "products in LDS" variants are kept for A/B runs (tools/ab_spmv.py).
 // No MFMA: arithmetic intensity is 0.13 flop/B; the bound is HBM (≈8 TB/s peak).
 #include "mgs_internal.hpp"
 
@@ -39,15 +40,43 @@ __device__ __forceinline__ void epilogue(int row, double s, const double *__rest
   else out[row] = x[row] + (omega * dinv[row]) * (b[row] - s);
 }
 
-template <int OP, bool NT, int LANES>
+// vector types for 16-byte wide streaming loads
+typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef int int2_t __attribute__((ext_vector_type(2)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// Workgroup → row-block map.  (1) XCD-contiguous: workgroups are dealt round-robin over the 8
+// XCDs, so XCD x = bid & 7 sweeps the x-th eighth of the row blocks.  (2) Optional strip-major
+// sweep inside an XCD for operators with a far band at ±D row blocks (the e±N² planes of the
+// 7-point stencil): instead of plane after plane, a strip of S row blocks is followed through all
+// planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
+// p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
+struct BlockMap { int nblocks, chunk, remap, D, S, P; };
+__device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
+  if (!m.remap) return bid < m.nblocks ? bid : -1;
+  const int xcd = bid & 7, idx = bid >> 3;
+  int lb = idx;
+  if (m.D > 0) {
+    const int ps = m.P * m.S;
+    const int s = idx / ps, rem = idx - s * ps;
+    const int p = rem / m.S, t = rem - p * m.S;
+    const int off = s * m.S + t;
+    if (off >= m.D) return -1;
+    lb = p * m.D + off;
+  }
+  if (lb >= m.chunk) return -1;
+  const int vb = xcd * m.chunk + lb;
+  return vb < m.nblocks ? vb : -1;
+}
+
+template <int OP, bool NT, int LANES, int CHUNK>
 __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
-    double *__restrict__ out, int cap, int nblocks, int chunk, int remap) {
+    double *__restrict__ out, int cap, BlockMap bm) {
   extern __shared__ double prod[];
-  const int bid = blockIdx.x;
-  const int vb = remap ? (bid & 7) * chunk + (bid >> 3) : bid;
-  if (vb >= nblocks) return;
+  const int vb = map_block(bm, blockIdx.x);
+  if (vb < 0) return;
   const int r0 = vb * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
@@ -58,14 +87,44 @@ __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
     int my_lo = 0, my_hi = 0;
     if (row < r1) { my_lo = rowptr[row] - lo; my_hi = rowptr[row + 1] - lo; }
     // phase 1: coalesced stream of the block's matrix slice, products to LDS
-    const int *__restrict__ cp = col + lo;
-    const double *__restrict__ vp = val + lo;
-    const int cnt = hi - lo;
+    if (CHUNK == 1) {
+      const int *__restrict__ cp = col + lo;
+      const double *__restrict__ vp = val + lo;
+      const int cnt = hi - lo;
 #pragma unroll 8
-    for (int k = tid; k < cnt; k += RB) {
-      const int c = ld_stream<NT>(cp + k);
-      const double v = ld_stream<NT>(vp + k);
-      prod[k] = v * x[c];
+      for (int k = tid; k < cnt; k += RB) {
+        const int c = ld_stream<NT>(cp + k);
+        const double v = ld_stream<NT>(vp + k);
+        prod[k] = v * x[c];
+      }
+    } else if (CHUNK == 2) {
+      // 2 entries per lane per step: val as one 16-byte load, col as one 8-byte load.  The slice is
+      // widened to even element offsets (allocation is padded; out-of-slice lanes are masked).
+      const int start = lo & ~1;
+      const int nch = (hi - start + 1) >> 1;
+#pragma unroll 4
+      for (int c = tid; c < nch; c += RB) {
+        const int k = start + 2 * c;
+        const int2_t cc = ld_stream<NT>(reinterpret_cast<const int2_t *>(col + k));
+        const double2_t vv = ld_stream<NT>(reinterpret_cast<const double2_t *>(val + k));
+        if (k >= lo) prod[k - lo] = vv.x * x[cc.x];
+        if (k + 1 < hi) prod[k + 1 - lo] = vv.y * x[cc.y];
+      }
+    } else {
+      // 4 entries per lane per step: col as one 16-byte load, val as two 16-byte loads
+      const int start = lo & ~3;
+      const int nch = (hi - start + 3) >> 2;
+#pragma unroll 2
+      for (int c = tid; c < nch; c += RB) {
+        const int k = start + 4 * c;
+        const int4_t cc = ld_stream<NT>(reinterpret_cast<const int4_t *>(col + k));
+        const double2_t v01 = ld_stream<NT>(reinterpret_cast<const double2_t *>(val + k));
+        const double2_t v23 = ld_stream<NT>(reinterpret_cast<const double2_t *>(val + k + 2));
+        if (k >= lo && k < hi) prod[k - lo] = v01.x * x[cc.x];
+        if (k + 1 >= lo && k + 1 < hi) prod[k + 1 - lo] = v01.y * x[cc.y];
+        if (k + 2 >= lo && k + 2 < hi) prod[k + 2 - lo] = v23.x * x[cc.z];
+        if (k + 3 >= lo && k + 3 < hi) prod[k + 3 - lo] = v23.y * x[cc.w];
+      }
     }
     __syncthreads();
     // phase 2: sequential per-row sum in ascending column order
@@ -88,25 +147,113 @@ __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
   }
 }
 
-__global__ void plan_kernel(int n, const int *__restrict__ rowptr, int nblocks, int *__restrict__ out /*[0]=max block nnz,[1]=max row len*/) {
+// Variant B ("slice in LDS, row-parallel gather").  Phase 1 parks the block's raw val/col slice
+// in LDS (coalesced 16-byte / 8-byte non-temporal loads, no dependent gather in the streaming
+// phase).  Phase 2: lane t walks row t; on step q the 64 lanes of a wave gather x[col] for 64
+// CONSECUTIVE rows, which for stencil-like operators is one contiguous run (4–5 cache lines per
+// wave instruction instead of ~12 when 64 consecutive entries are gathered) — 2.5× less L2→L1
+// traffic and TA work for the x gather.  Sum order is still the ascending column order of the
+// row, so the result stays bit-identical to the scalar CPU loop.
+template <int OP, bool NT, int LANES>
+__global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
+    double *__restrict__ out, int cap, BlockMap bm) {
+  extern __shared__ double lds_raw[];
+  const int vb = map_block(bm, blockIdx.x);
+  if (vb < 0) return;
+  const int r0 = vb * RB;
+  const int r1 = min(r0 + RB, n);
+  const int tid = threadIdx.x;
+  const int lo = rowptr[r0];
+  const int hi = rowptr[r1];
+  if (hi - lo <= cap) {
+    double *__restrict__ vals = lds_raw;                                   // cap + 2 doubles
+    int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);   // cap + 2 ints
+    const int row = r0 + tid;
+    const int start = lo & ~1;                 // even element offset → 16-byte aligned val pairs
+    int my_a = 0, my_e = 0;
+    double bi = 0.0, di = 0.0, xi = 0.0;
+    if (row < r1) {
+      my_a = rowptr[row] - start; my_e = rowptr[row + 1] - start;
+      if (OP != MGS_OP_SPMV) bi = b[row];
+      if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
+    }
+    const int nch = (hi - start + 1) >> 1;
+#pragma unroll 4
+    for (int c = tid; c < nch; c += RB) {
+      const int k = start + 2 * c;
+      const int2_t cc = ld_stream<NT>(reinterpret_cast<const int2_t *>(col + k));
+      const double2_t vv = ld_stream<NT>(reinterpret_cast<const double2_t *>(val + k));
+      *reinterpret_cast<double2_t *>(vals + 2 * c) = vv;
+      *reinterpret_cast<int2_t *>(cols + 2 * c) = cc;
+    }
+    __syncthreads();
+    if (row < r1) {
+      double s = 0.0;
+      int k = my_a;
+      // rows of up to 8 entries: all gathers in flight before the first add
+      for (; k + 8 <= my_e; k += 8) {
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = x[cols[k + q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += vals[k + q] * xv[q];
+      }
+      {
+        double xv[8];
+        const int rem = my_e - k;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = q < rem ? x[cols[k + q]] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+      }
+      if (OP == MGS_OP_SPMV) out[row] = s;
+      else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
+      else out[row] = xi + (omega * di) * (bi - s);
+    }
+  } else {
+    const int sub = tid / LANES, lane = tid % LANES;
+    for (int row = r0 + sub; row < r1; row += RB / LANES) {
+      double s = 0.0;
+      const int e = rowptr[row + 1];
+      for (int k = rowptr[row] + lane; k < e; k += LANES) s += val[k] * x[col[k]];
+#pragma unroll
+      for (int off = LANES / 2; off > 0; off >>= 1) s += __shfl_down(s, off, LANES);
+      if (lane == 0) epilogue<OP>(row, s, x, b, dinv, omega, out);
+    }
+  }
+}
+
+__global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
+                            int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns*/) {
   int vb = blockIdx.x * blockDim.x + threadIdx.x;
-  int mx = 0, mr = 0;
+  int mx = 0, mr = 0, far = 0;
   if (vb < nblocks) {
     int r0 = vb * RB, r1 = min(r0 + RB, n);
     mx = rowptr[r1] - rowptr[r0];
-    for (int r = r0; r < r1; ++r) mr = max(mr, rowptr[r + 1] - rowptr[r]);
+    for (int r = r0; r < r1; ++r) {
+      const int a = rowptr[r], e = rowptr[r + 1];
+      mr = max(mr, e - a);
+      if (e > a) {   // sorted row: extremes are the first entry and the last owned entry
+        far = max(far, r - col[a]);
+        int k = e - 1;
+        while (k > a && col[k] >= n) --k;
+        if (col[k] < n) far = max(far, col[k] - r);
+      }
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_down(mx, off)); mr = max(mr, __shfl_down(mr, off)); }
-  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicMax(&out[1], mr); }
+  for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_down(mx, off)); mr = max(mr, __shfl_down(mr, off)); far = max(far, __shfl_down(far, off)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicMax(&out[1], mr); atomicMax(&out[2], far); }
 }
 
-template <int OP, bool NT>
+template <int OP, bool NT, int CHUNK>
 int launch_lanes(const mgs_csr *A, int lanes, dim3 grid, size_t lds, const double *x, const double *b,
-                 const double *dinv, double omega, double *out, int cap, int nblocks, int chunk, int remap) {
+                 const double *dinv, double omega, double *out, int cap, BlockMap bm) {
   hipStream_t s = A->ctx->stream;
-#define L_(LN)                                                                                        \
-  hipLaunchKernelGGL((csr_rowblock_kernel<OP, NT, LN>), grid, dim3(RB), lds, s, A->rows, A->rowptr,   \
-                     A->col, A->val, x, b, dinv, omega, out, cap, nblocks, chunk, remap)
+#define L_(LN)                                                                                             \
+  hipLaunchKernelGGL((csr_rowblock_kernel<OP, NT, LN, CHUNK>), grid, dim3(RB), lds, s, A->rows, A->rowptr, \
+                     A->col, A->val, x, b, dinv, omega, out, cap, bm)
   switch (lanes) {
     case 4: L_(4); break;
     case 8: L_(8); break;
@@ -116,6 +263,34 @@ int launch_lanes(const mgs_csr *A, int lanes, dim3 grid, size_t lds, const doubl
   }
 #undef L_
   return MGS_OK;
+}
+template <int OP, bool NT>
+int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const double *b,
+                 const double *dinv, double omega, double *out, int cap, BlockMap bm) {
+  hipStream_t s = A->ctx->stream;
+  const size_t lds = (size_t)(cap > 0 ? cap + 2 : 2) * 12 + 16;
+#define L_(LN)                                                                                             \
+  hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN>), grid, dim3(RB), lds, s, A->rows, A->rowptr, \
+                     A->col, A->val, x, b, dinv, omega, out, cap, bm)
+  switch (lanes) {
+    case 4: L_(4); break;
+    case 8: L_(8); break;
+    case 16: L_(16); break;
+    case 32: L_(32); break;
+    default: L_(64); break;
+  }
+#undef L_
+  return MGS_OK;
+}
+template <int OP, bool NT>
+int launch_chunk(const mgs_csr *A, int chunk_elems, int lanes, dim3 grid, size_t lds, const double *x, const double *b,
+                 const double *dinv, double omega, double *out, int cap, BlockMap bm) {
+  switch (chunk_elems) {
+    case 0: return launch_slice<OP, NT>(A, lanes, grid, x, b, dinv, omega, out, cap, bm);
+    case 1: return launch_lanes<OP, NT, 1>(A, lanes, grid, lds, x, b, dinv, omega, out, cap, bm);
+    case 2: return launch_lanes<OP, NT, 2>(A, lanes, grid, lds, x, b, dinv, omega, out, cap, bm);
+    default: return launch_lanes<OP, NT, 4>(A, lanes, grid, lds, x, b, dinv, omega, out, cap, bm);
+  }
 }
 
 }  // namespace
@@ -127,14 +302,15 @@ int mgs_plan_csr(mgs_csr *A) {
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
   int *d = nullptr;
-  MGS_TRY(mgs_dev_alloc(ctx, &d, 2));
-  MGS_HIP(ctx, hipMemsetAsync(d, 0, 2 * sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, nblocks, d);
-  int h[2] = {0, 0};
+  MGS_TRY(mgs_dev_alloc(ctx, &d, 3));
+  MGS_HIP(ctx, hipMemsetAsync(d, 0, 3 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, A->col, nblocks, d);
+  int h[3] = {0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_HIP(ctx, hipFree(d));
   A->max_row_len = h[1];
+  A->far_band = h[2];
   A->lds_cap = h[0] < LDS_CAP_MAX ? h[0] : LDS_CAP_MAX;
   if (A->lds_cap < 64) A->lds_cap = 64;
   return MGS_OK;
@@ -144,10 +320,23 @@ int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b
                       double omega, double *out) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0) return MGS_OK;
-  const int nblocks = (A->rows + RB - 1) / RB;
-  const int remap = ctx->opt_xcd_remap && nblocks >= 64;
-  const int chunk = (nblocks + 7) / 8;
-  dim3 grid(remap ? chunk * 8 : nblocks);
+  BlockMap bm;
+  bm.nblocks = (A->rows + RB - 1) / RB;
+  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
+  bm.chunk = (bm.nblocks + 7) / 8;
+  bm.D = 0; bm.S = 0; bm.P = 0;
+  int per_xcd = bm.chunk;
+  // strip-major sweep when three x planes (3·far·8 B) overflow an XCD's L2 share and the XCD's
+  // range holds at least two planes
+  if (bm.remap && ctx->opt_strip != 0) {
+    const int D = (A->far_band + RB - 1) / RB;
+    if (D >= 256 && bm.chunk >= 2 * D) {
+      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
+      const int strips = (D + bm.S - 1) / bm.S;
+      per_xcd = strips * bm.P * bm.S;
+    }
+  }
+  dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   int cap = ctx->opt_spmv_variant == 1 ? -1 : A->lds_cap;
   size_t lds = sizeof(double) * (size_t)(cap > 0 ? cap : 1);
   // lanes per row of the long-row path: next power of two ≥ mean row length, in [4,64]
@@ -155,9 +344,12 @@ int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b
   int lanes = 4;
   while (lanes < 64 && lanes < mean) lanes <<= 1;
   const bool nt = ctx->opt_nontemporal != 0;
-#define OP_(O)                                                                                           \
-  (nt ? launch_lanes<O, true>(A, lanes, grid, lds, x, b, dinv, omega, out, cap, nblocks, chunk, remap)    \
-      : launch_lanes<O, false>(A, lanes, grid, lds, x, b, dinv, omega, out, cap, nblocks, chunk, remap))
+  // variants: 0 auto, 1 forced sub-wavefront rows, 2/3/4 = products-in-LDS with 1/2/4 entries per lane, 5 = slice-in-LDS
+  int chunk_elems = 0;
+  switch (ctx->opt_spmv_variant) { case 2: chunk_elems = 1; break; case 3: chunk_elems = 2; break; case 4: chunk_elems = 4; break; default: chunk_elems = 0; }
+#define OP_(O)                                                                                                   \
+  (nt ? launch_chunk<O, true>(A, chunk_elems, lanes, grid, lds, x, b, dinv, omega, out, cap, bm)                 \
+      : launch_chunk<O, false>(A, chunk_elems, lanes, grid, lds, x, b, dinv, omega, out, cap, bm))
   switch (op) {
     case MGS_OP_SPMV: OP_(MGS_OP_SPMV); break;
     case MGS_OP_RESIDUAL: OP_(MGS_OP_RESIDUAL); break;

@@ -60,6 +60,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "nontemporal") ctx->opt_nontemporal = value;
   else if (k == "spmv_variant") ctx->opt_spmv_variant = value;
   else if (k == "graph") ctx->opt_graph = value;
+  else if (k == "strip") ctx->opt_strip = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
 }

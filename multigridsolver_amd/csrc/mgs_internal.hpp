@@ -27,6 +27,7 @@ struct mgs_ctx {
   int opt_nontemporal = 1;
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   mgs_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
 };
@@ -41,6 +42,7 @@ struct mgs_csr {
   bool owns = true;
   // launch plan of the row-block stream kernel (computed at upload)
   int max_row_len = 0;
+  int far_band = 0;  // max |col - row| over owned columns
   int lds_cap = 0;  // products staged per block (doubles)
 };
 
