@@ -19,6 +19,10 @@ ALG = {"spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi
        "axpby(calibration)": 24 * n}
 
 
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return name.split("(")[0]
@@ -26,15 +30,15 @@ def short(name):
 
 def classify(name):
     s = short(name)
-    if s.startswith("csr_rowblock_kernel<0"): return "spmv"
-    if s.startswith("csr_rowblock_kernel<1"): return "residual"
-    if s.startswith("csr_rowblock_kernel<2"): return "jacobi"
+    for pre in ("csr_rowblock_kernel<", "csr_rowblock_slice_kernel<"):
+        if s.startswith(pre):
+            return {"0": "spmv", "1": "residual", "2": "jacobi"}.get(s[len(pre)], None)
     if s.startswith("axpby_kernel"): return "axpby(calibration)"
     return None
 
 
-stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0])))
-trace = list(csv.DictReader(open(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0])))
+stats = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))))
+trace = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv")))))
 fine = collections.defaultdict(list)   # fine-level dispatches only (grid covers n rows)
 for r in trace:
     k = classify(r["Kernel_Name"])
@@ -44,7 +48,7 @@ for r in trace:
 
 def pmc(sub, counter):
     out = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0])):
+    for r in csv.DictReader(open(newest(os.path.join(src, sub, "*", "*_counter_collection.csv")))):
         k = classify(r["Kernel_Name"])
         if k and r["Counter_Name"] == counter and (int(r["Grid_Size"]) >= n or k.startswith("axpby")):
             out[k].append(float(r["Counter_Value"]))
@@ -86,5 +90,5 @@ with open(os.path.join(REPO, "profiles", f"{tag}_summary.md"), "w") as f:
         f.write(f"| {r['name']} | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.1f} | {r['pct']:.2f} |\n")
 # keep the raw stats CSV too (small)
 import shutil
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0], os.path.join(REPO, "profiles", f"{tag}_kernel_stats.csv"))
+shutil.copy(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), os.path.join(REPO, "profiles", f"{tag}_kernel_stats.csv"))
 print(open(os.path.join(REPO, "profiles", f"{tag}_summary.md")).read())
