@@ -48,6 +48,25 @@ def residual_bytes(n, nnz):
     return 12 * nnz + 28 * n + 4
 
 
+def pmc_traffic(kernel="spmv", grid=512):
+    """HBM/fabric bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC
+    summary (profiles/*_summary.json: FETCH_SIZE/WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md §HBM prescribes).  None if no summary matches this grid."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("grid") != grid:
+                continue
+            for r in d["fine_level_kernels"]:
+                if r["kernel"] == kernel:
+                    best = (r["traffic_bytes"], os.path.basename(f))
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
 def cpu_baseline(mg, args):
     """CPU oracle V-cycle (port of the same cycle, 1 thread) on a bounded sample: a smaller grid
     with the hierarchy the device built for it, scaled by the row ratio.  Also times the
@@ -204,7 +223,8 @@ def main():
                    "grid": N, "rows": n, "nnz": nnz, "levels": levels, "parallelism": "1 GPU", "setup_seconds": t_setup},
         "spmv_hbm_gbps": spmv_gbps,
         "roofline": {"bound": "hbm", "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": spmv_gbps / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "csr_rowblock_kernel<SPMV> (fine level)", "algorithmic_bytes_per_launch": spmv_bytes(n, nnz),
+                     "traffic": (pmc_traffic("spmv", N) or (None, None))[0], "traffic_source": (pmc_traffic("spmv", N) or (None, None))[1],
+                     "kernel": "csr_rowblock_slice_kernel<SPMV> (fine level)", "algorithmic_bytes_per_launch": spmv_bytes(n, nnz),
                      "ms_per_launch": ms_spmv,
                      "other_kernels": {"residual": {"ms": ms_res, "gbps": gbps(residual_bytes(n, nnz), ms_res)},
                                        "jacobi": {"ms": ms_jac, "gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},

@@ -406,7 +406,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes):
                           "sharded_levels": len(sh.plans), "total_levels": sh.nlev, "setup_seconds": t_setup},
                "spmv_hbm_gbps": spmv_bytes(n, nnz) / (ms_x * 1e-3) / 1e9,
                "roofline": {"bound": "hbm", "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0, "traffic": None,
-                            "kernel": "csr_rowblock_kernel<SPMV> (rank 0 shard, per-GPU rate)", "algorithmic_bytes_per_launch": loc_bytes,
+                            "kernel": "csr_rowblock_slice_kernel<SPMV> (rank 0 shard, per-GPU rate)", "algorithmic_bytes_per_launch": loc_bytes,
                             "ms_per_launch": ms_k, "ms_spmv_with_halo_exchange": ms_x},
                "solve_check": {"bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol},
                "cpu_baseline": None}

@@ -291,3 +291,29 @@ def test_properties_at_scale(ctx, mg):
         assert np.array_equal(A.spmv(x).numpy(), ax.numpy())
     finally:
         ctx.set_option("xcd_remap", 1)
+
+
+def test_cpp_dropin_driver(orc, inputs, golden, tmp_path):
+    """mgs_bicg = the reference's `./bicg <name> <cpu|gpu>` CLI (bicg.cpp:138-180) on the C++ host
+    face (mgs_host.hpp) over the C-ABI: same paths, same two [info] lines; solution checked."""
+    import os, re, shutil, subprocess
+    from conftest import REPO
+    exe = os.path.join(REPO, "multigridsolver_amd", "cpp", "mgs_bicg")
+    assert os.path.exists(exe), "build() must compile the C++ driver"
+    root = tmp_path / "tree"; (root / "matrices").mkdir(parents=True); (root / "src" / "common").mkdir(parents=True)
+    shutil.copy(inputs["poisson10000"], root / "matrices" / "poisson10000.mtx")
+    shutil.copy(inputs["poisson10000promatrix"], root / "matrices" / "poisson10000promatrix_cpu.mtx")
+    Ao = orc.Csr.read(inputs["poisson10000"]); b = orc.rand_rhs(10000)
+    for extra, tag in [({}, "cpu"), ({"MGS_GENERIC": "1"}, "cpu"), ({}, "device")]:
+        dump = str(tmp_path / "x.bin")
+        env = dict(os.environ, MGS_DUMP_X=dump, **extra)
+        r = subprocess.run([exe, "poisson10000", tag], cwd=root / "src" / "common", capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "Read matrix from file: ../../matrices/poisson10000.mtx" in r.stderr and "[time] " in r.stderr and "BiCGStab_SolveTimer" in r.stderr
+        m_tol = re.search(r"\[info\] .*Tolerance\s+: ([0-9.eE+-]+)\.\n", r.stdout); m_it = re.search(r"Number of iterations BICG\s+: (\d+)\.", r.stdout)
+        assert m_tol and m_it, r.stdout
+        assert float(m_tol.group(1)) < 1e-6 and 1 <= int(m_it.group(1)) < 100
+        x = np.fromfile(dump, dtype="<f8")
+        assert np.linalg.norm(Ao.residual(x, b)) / np.linalg.norm(b) < 1.5e-6
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Incorrect number of arguments." in r.stdout       # bicg.cpp:140-144
