@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
     VectorXd x(A.rows());
     x.setZero();
     std::vector<double> bh((size_t)A.rows());
+    srand(0);   // the reference draws nothing between srand(0) (:139) and this loop; runtime start-up here might
     for (int i = 0; i < A.rows(); i++) bh[i] = rand() / (RAND_MAX + 0.0);
     VectorXd b(A.rows());
     b.upload(bh);
