@@ -67,6 +67,49 @@ def pmc_traffic(kernel="spmv", grid=512):
     return best
 
 
+def bundled_cases(mg, args):
+    """V-cycles/s on the reference's bundled operators (BASELINE.json configs[1..2]; cache-resident,
+    launch-latency bound — reported as time, not as an HBM fraction)."""
+    import gzip
+    import shutil
+    import tempfile
+    inp = os.path.join(REPO, "tests", "golden", "inputs")
+    out = {}
+    ctx = mg.Context(0)
+    tmp = tempfile.mkdtemp(prefix="mgs_bench_")
+    try:
+        cases = []
+        pP = os.path.join(inp, "poisson10000promatrix.mtx")
+        if os.path.exists(pP):
+            cases.append(("poisson10000 + bundled promatrix (configs[1])", ctx.poisson2d(100), pP))
+        gz = os.path.join(inp, "CSky3d30.mtx.gz")
+        if os.path.exists(gz):
+            path = os.path.join(tmp, "CSky3d30.mtx")
+            with gzip.open(gz, "rb") as f, open(path, "wb") as g:
+                shutil.copyfileobj(f, g)
+            A3 = mg.Csr.from_mtx(ctx, path)
+            cases.append(("CSky3d30 + P from the reference CPU setup", A3, os.path.join(inp, "CSky3d30promatrix_cpu.mtx")))
+            cases.append(("CSky3d30, hierarchy aggregated on device (configs[2])", A3, None))
+        for name, A, Ppath in cases:
+            h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2)
+            if Ppath:
+                h.push_P(mg.Csr.from_mtx(ctx, Ppath))
+            h.coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+            n = A.shape[0]
+            b = ctx.vec(n).rand(seed=0); x = ctx.vec(n)
+            h.time_vcycle(b, x, reps=20)
+            ms = min(h.time_vcycle(b, x, reps=200) for _ in range(3))
+            xs = ctx.vec(n)
+            st, it, tol = mg.bicgstab(A, xs, b, h, 2000, 1e-10)
+            out[name] = {"rows": n, "nnz": A.nnz, "levels": [h.level_shape(l)[0] for l in range(h.nlev)], "ms_per_vcycle": ms,
+                         "vcycles_per_s": 1e3 / ms, "bicgstab_iterations_to_1e-10": it, "bicgstab_status": st, "achieved_tol": tol}
+            del h, b, x, xs
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        ctx.close()
+    return out
+
+
 def cpu_baseline(mg, args):
     """CPU oracle V-cycle (port of the same cycle, 1 thread) on a bounded sample: a smaller grid
     with the hierarchy the device built for it, scaled by the row ratio.  Also times the
@@ -234,6 +277,10 @@ def main():
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
+    try:
+        out["bundled_matrices"] = bundled_cases(mg, args)
+    except Exception as e:  # noqa: BLE001
+        log("bundled cases failed:", repr(e))
     if not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(mg, args)
