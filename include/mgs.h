@@ -206,6 +206,12 @@ int mgs_halo_pack(mgs_ctx *ctx, const mgs_vec *x, const int *send_idx_dev, int64
  * n_halo entries and the callee must fill x_dev[n_loc..] on ctx's stream.             */
 typedef int (*mgs_halo_fn)(void *user, int level, void *x_dev);
 int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user);
+/* Split-phase form: begin(user, level, x) packs and STARTS the exchange, end(...) waits for it.
+ * Between the two the library launches the kernel on the shard's interior row blocks (those that
+ * read no halo column), afterwards on the boundary row blocks — the exchange hides behind ~97 %
+ * of the rows of a plane-sharded stencil operator.  Falls back to fn for levels whose halo
+ * readers are not a prefix + suffix of the row range.                                          */
+int mgs_hier_set_halo_exchange_split(mgs_hier *h, mgs_halo_fn begin, mgs_halo_fn end, void *user);
 /* Building blocks of a row-sharded hierarchy (one process per GPU; orchestration in
  * multigridsolver_amd/dist.py).  mgs_aggregate_shard: pairwise aggregation of the OWNED
  * rows only (aggregates never straddle a shard; couplings to halo columns enter s_i and the

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mgs_hier_push_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_xfer_from_agg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(C.c_void_p)]),
     "mgs_hier_set_coarse_solver": (C.c_int, [C.c_void_p, COARSE_FN, C.c_void_p]),
+    "mgs_hier_set_halo_exchange_split": (C.c_int, [C.c_void_p, HALO_FN, HALO_FN, C.c_void_p]),
     "mgs_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mgs_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),
     "mgs_time_vcycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),

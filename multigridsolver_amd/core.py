@@ -310,6 +310,18 @@ class Hierarchy:
     def time_vcycle(self, b, x, reps=10):
         ms = C.c_double(); check(lib().mgs_time_vcycle(self.h, b.h, x.h, reps, C.byref(ms)), self.ctx.h); return ms.value
 
+    def set_halo_exchange_split(self, begin, end):
+        """begin(level, x_dev_ptr) starts the exchange, end(level, x_dev_ptr) waits for it"""
+        def mk(fn):
+            def _cb(_u, level, ptr):
+                try:
+                    fn(level, ptr); return 0
+                except Exception:  # noqa: BLE001
+                    import traceback; traceback.print_exc(); return 1
+            return HALO_FN(_cb)
+        self._cb2 = (mk(begin), mk(end))
+        check(lib().mgs_hier_set_halo_exchange_split(self.h, self._cb2[0], self._cb2[1], None), self.ctx.h)
+
     def set_halo_exchange(self, fn):
         """fn(level:int, x_dev_ptr:int) -> None"""
         def _cb(_u, level, ptr):

@@ -51,7 +51,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // 7-point stencil): instead of plane after plane, a strip of S row blocks is followed through all
 // planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
 // p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
-struct BlockMap { int nblocks, chunk, remap, D, S, P; };
+struct BlockMap { int nblocks, chunk, remap, D, S, P, base; };   // base: first row block of the launched range
 __device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
   if (!m.remap) return bid < m.nblocks ? bid : -1;
   const int xcd = bid & 7, idx = bid >> 3;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
   extern __shared__ double prod[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
-  const int r0 = vb * RB;
+  const int r0 = (bm.base + vb) * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
   const int lo = rowptr[r0];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
-  const int r0 = vb * RB;
+  const int r0 = (bm.base + vb) * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
   const int lo = rowptr[r0];
@@ -226,10 +226,12 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 }
 
 __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
-                            int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns*/) {
+                            int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
+                                                    [3]=#row blocks touching halo columns,[4]=min block without halo,[5]=max block without halo*/) {
   int vb = blockIdx.x * blockDim.x + threadIdx.x;
   int mx = 0, mr = 0, far = 0;
   if (vb < nblocks) {
+    bool halo = false;
     int r0 = vb * RB, r1 = min(r0 + RB, n);
     mx = rowptr[r1] - rowptr[r0];
     for (int r = r0; r < r1; ++r) {
@@ -238,10 +240,13 @@ __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__
       if (e > a) {   // sorted row: extremes are the first entry and the last owned entry
         far = max(far, r - col[a]);
         int k = e - 1;
+        if (col[k] >= n) halo = true;
         while (k > a && col[k] >= n) --k;
         if (col[k] < n) far = max(far, col[k] - r);
       }
     }
+    if (halo) atomicAdd(&out[3], 1);
+    else { atomicMin(&out[4], vb); atomicMax(&out[5], vb); }
   }
   for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_down(mx, off)); mr = max(mr, __shfl_down(mr, off)); far = max(far, __shfl_down(far, off)); }
   if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicMax(&out[1], mr); atomicMax(&out[2], far); }
@@ -302,15 +307,26 @@ int mgs_plan_csr(mgs_csr *A) {
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
   int *d = nullptr;
-  MGS_TRY(mgs_dev_alloc(ctx, &d, 3));
-  MGS_HIP(ctx, hipMemsetAsync(d, 0, 3 * sizeof(int), ctx->stream));
+  MGS_TRY(mgs_dev_alloc(ctx, &d, 6));
+  const int init[6] = {0, 0, 0, 0, 0x7fffffff, -1};
+  MGS_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, A->col, nblocks, d);
-  int h[3] = {0, 0, 0};
+  int h[6] = {0, 0, 0, 0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_HIP(ctx, hipFree(d));
   A->max_row_len = h[1];
   A->far_band = h[2];
+  // row blocks that read halo columns: usable for overlap when they form a prefix + suffix of the shard
+  A->halo_lo_blocks = A->halo_hi_blocks = 0; A->halo_split_ok = false;
+  if (A->cols > A->rows) {
+    if (h[5] < 0) { A->halo_lo_blocks = nblocks; A->halo_split_ok = false; }          // every block touches the halo
+    else {
+      const int lo_cnt = h[4], hi_cnt = nblocks - 1 - h[5];
+      A->halo_lo_blocks = lo_cnt; A->halo_hi_blocks = hi_cnt;
+      A->halo_split_ok = (h[3] == lo_cnt + hi_cnt) && (nblocks - lo_cnt - hi_cnt) > 0;
+    }
+  }
   A->lds_cap = h[0] < LDS_CAP_MAX ? h[0] : LDS_CAP_MAX;
   if (A->lds_cap < 64) A->lds_cap = 64;
   return MGS_OK;
@@ -318,10 +334,17 @@ int mgs_plan_csr(mgs_csr *A) {
 
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,
                       double omega, double *out) {
+  return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, (A->rows + RB - 1) / RB);
+}
+
+// the same kernels on the row blocks [blk_lo, blk_hi) only (interior / boundary split of a row shard)
+int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,
+                            double omega, double *out, int blk_lo, int blk_hi) {
   mgs_ctx *ctx = A->ctx;
-  if (A->rows == 0) return MGS_OK;
+  if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
   BlockMap bm;
-  bm.nblocks = (A->rows + RB - 1) / RB;
+  bm.base = blk_lo;
+  bm.nblocks = blk_hi - blk_lo;
   bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
   bm.chunk = (bm.nblocks + 7) / 8;
   bm.D = 0; bm.S = 0; bm.P = 0;

@@ -316,6 +316,11 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2) {
   return MGS_OK;
 }
 int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user) { h->halo = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
+int mgs_hier_set_halo_exchange_split(mgs_hier *h, mgs_halo_fn begin, mgs_halo_fn end, void *user) {
+  MGS_CHECK(h->ctx, (begin == nullptr) == (end == nullptr), MGS_ERR_INVALID, "split exchange needs both begin and end");
+  h->halo_begin = begin; h->halo_end = end; h->halo_user = user; drop_graph(h);
+  return MGS_OK;
+}
 int mgs_hier_nlev(const mgs_hier *h) { return (int)h->lev.size(); }
 int mgs_hier_level_shape(const mgs_hier *h, int l, int *rows, int64_t *nnz) {
   MGS_CHECK(h->ctx, l >= 0 && l < (int)h->lev.size(), MGS_ERR_INVALID, "level %d out of range", l);
@@ -433,12 +438,35 @@ int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
 //   (coarsest: A_c⁻¹, bicg.cpp:35-36,48);  x ← x + P e_c (bicg.cpp:48);  ν2 × { x ← x + ωD⁻¹(b − Ax) }
 // From x = 0 the first pre-sweep is x = (ωD⁻¹)b, the residual is b and x + P e_c is P e_c —
 // bit-identical shortcuts that skip one SpMV-sized pass each.
+int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const double *b, double *x);
+
 static int halo_x(mgs_hier *h, int l, double *x) {
   if (!h->halo) return MGS_OK;
   int rc = h->halo(h->halo_user, l, x);
   return rc ? mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange callback failed at level %d (%d)", l, rc) : MGS_OK;
 }
-int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const double *b, double *x);
+// one SpMV-shaped kernel on level l with x's halo refreshed first; with split-phase callbacks the
+// interior row blocks run while the exchange is in flight
+static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out) {
+  if (!h->halo && !h->halo_begin) return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
+  if (h->halo_begin && A->halo_split_ok) {
+    const int nb = (A->rows + 255) / 256, lo = A->halo_lo_blocks, hi = nb - A->halo_hi_blocks;
+    int rc = h->halo_begin(h->halo_user, l, x);
+    if (rc) return mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange (begin) failed at level %d (%d)", l, rc);
+    MGS_TRY(mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, lo, hi));
+    rc = h->halo_end(h->halo_user, l, x);
+    if (rc) return mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange (end) failed at level %d (%d)", l, rc);
+    MGS_TRY(mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, lo));
+    return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, hi, nb);
+  }
+  if (h->halo) MGS_TRY(halo_x(h, l, x));
+  else {   // split callbacks only, but this level's halo readers are scattered: exchange, then one launch
+    int rc = h->halo_begin(h->halo_user, l, x);
+    if (!rc) rc = h->halo_end(h->halo_user, l, x);
+    if (rc) return mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange failed at level %d (%d)", l, rc);
+  }
+  return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
+}
 
 static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero_guess) {
   mgs_ctx *ctx = h->ctx;
@@ -457,14 +485,13 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   for (int s = 0; s < h->nu1; ++s) {
     if (zero) { MGS_TRY(k_jacobi_zero(ctx, n, h->omega, L.dinv->d, b, cur)); zero = false; }
     else {
-      MGS_TRY(halo_x(h, l, cur));
-      MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
+      MGS_TRY(sharded_op(h, l, L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
       std::swap(cur, alt);
     }
   }
   const double *r = L.r->d;
   if (zero) r = b;                                       // r = b − A·0
-  else { MGS_TRY(halo_x(h, l, cur)); MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_RESIDUAL, cur, b, nullptr, 0.0, L.r->d)); }
+  else MGS_TRY(sharded_op(h, l, L.A, MGS_OP_RESIDUAL, cur, b, nullptr, 0.0, L.r->d));
   // restriction
   if (L.T->aggregation) MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, r, C.b->d));
   else MGS_TRY(mgs_launch_csr_op(L.T->Pt, MGS_OP_SPMV, r, nullptr, nullptr, 0.0, C.b->d));
@@ -477,8 +504,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     MGS_TRY(k_axpby(ctx, n, 1.0, L.r->d, 1.0, cur));
   }
   for (int s = 0; s < h->nu2; ++s) {
-    MGS_TRY(halo_x(h, l, cur));
-    MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
+    MGS_TRY(sharded_op(h, l, L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
     std::swap(cur, alt);
   }
   if (cur != x) MGS_HIP(ctx, hipMemcpyAsync(x, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -498,7 +524,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
-  const bool use_graph = ctx->opt_graph && !h->halo && !h->coarse;
+  const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {
@@ -535,7 +561,12 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
   mgs_vec xv, bv, phv, shv; view(x, xv); view(const_cast<mgs_vec *>(b), bv); view(phat, phv); view(shat, shv);
   const mgs_vec *xin = x;
   if (x->n < next) { MGS_TRY(mgs_vec_create(ctx, next, &xe)); guard.vs.push_back(&xe); MGS_TRY(mgs_vec_copy(&xv, xe)); xin = xe; }
-  auto halo0 = [&](mgs_vec *w) -> int { return (h && h->halo) ? h->halo(h->halo_user, 0, w->d) : 0; };
+  auto halo0 = [&](mgs_vec *w) -> int {
+    if (!h) return 0;
+    if (h->halo) return h->halo(h->halo_user, 0, w->d);
+    if (h->halo_begin) { int rc = h->halo_begin(h->halo_user, 0, w->d); return rc ? rc : h->halo_end(h->halo_user, 0, w->d); }
+    return 0;
+  };
   auto precond = [&](const mgs_vec *in, mgs_vec *out) -> int {       // M.solve (bicg.cpp:106,116)
     if (!h) { mgs_vec ov; view(out, ov); return mgs_vec_copy(in, &ov); }
     return mgs_vcycle(h, in, out, 1);

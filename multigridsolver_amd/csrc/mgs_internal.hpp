@@ -43,6 +43,8 @@ struct mgs_csr {
   // launch plan of the row-block stream kernel (computed at upload)
   int max_row_len = 0;
   int far_band = 0;  // max |col - row| over owned columns
+  int halo_lo_blocks = 0, halo_hi_blocks = 0;  // leading / trailing row blocks that read halo columns
+  bool halo_split_ok = false;                  // no other block does → interior rows can overlap the exchange
   int lds_cap = 0;  // products staged per block (doubles)
 };
 
@@ -87,6 +89,7 @@ struct mgs_hier {
   double *inv = nullptr;  // nc*nc dense inverse (row-major)
   mgs_halo_fn halo = nullptr;
   void *halo_user = nullptr;
+  mgs_halo_fn halo_begin = nullptr, halo_end = nullptr;   // split-phase exchange (overlap with interior rows)
   mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
   void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle
@@ -124,6 +127,8 @@ int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...);
 enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2 };
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b,
                       const double *dinv, double omega, double *out);
+int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b,
+                            const double *dinv, double omega, double *out, int blk_lo, int blk_hi);
 int mgs_plan_csr(mgs_csr *A);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);

@@ -156,11 +156,13 @@ class Comm:
         d.all_reduce(x, op=d.ReduceOp.SUM if op == "sum" else d.ReduceOp.MAX)
         a[:] = x.cpu().numpy()
 
-    def a2a_f64(self, recv, send, recv_counts, send_counts):
-        """recv/send: 1-D float64 torch tensors on self.device"""
+    def a2a_f64(self, recv, send, recv_counts, send_counts, async_op=False):
+        """recv/send: 1-D float64 torch tensors on self.device.  async_op: returns a work handle
+        (or None when the transfer already completed, i.e. on the host-staged path)."""
         d = self.dist
         if self.nccl or self.device.type == "cpu":
-            d.all_to_all_single(recv, send, recv_counts, send_counts)
+            w = d.all_to_all_single(recv, send, recv_counts, send_counts, async_op=async_op)
+            return w if async_op else None
         else:  # gloo with device buffers: stage through the host
             s = send.cpu(); r = self.torch.empty(recv.numel(), dtype=recv.dtype)
             d.all_to_all_single(r, s, recv_counts, send_counts)
@@ -196,7 +198,7 @@ class ShardedHierarchy:
         self.h = core.Hierarchy(A_local, omega, nu1, nu2)
         self.smoother = (omega, nu1, nu2)
         self.tail = None
-        self._views, self._bufs, self._keep, self._xc = {}, {}, [], {}
+        self._views, self._bufs, self._keep, self._xc, self._pending = {}, {}, [], {}, {}
         self.n_exchanges = 0
 
     # ---- device helpers
@@ -215,7 +217,7 @@ class ShardedHierarchy:
         plan.dev_send_idx = t.from_numpy(idx.astype(np.int32)).to(self.comm.device)
         self._bufs[level] = t.empty(max(len(idx), 1), dtype=t.float64, device=self.comm.device)
 
-    def _exchange(self, level, x_ptr):
+    def _exchange(self, level, x_ptr, async_op=False):
         """halo of x on `level`: pack kernel (gather of the owned rows peers need) on the context's
         stream, then one all_to_all straight into x's halo slots.  Everything per (level, pointer)
         is cached: the hot loop does two ctypes calls and one collective."""
@@ -230,14 +232,23 @@ class ShardedHierarchy:
             self._xc[key] = c
         ns, nr, xv, idx_p, buf_p, recv, send, rcnt, scnt = c
         if ns == 0 and nr == 0:
-            return
+            return None
         if ns:
             check(lib().mgs_halo_pack(self.ctx.h, xv.h, idx_p, ns, buf_p), self.ctx.h)
-        self.comm.a2a_f64(recv, send, rcnt, scnt)
         self.n_exchanges += 1
+        return self.comm.a2a_f64(recv, send, rcnt, scnt, async_op=async_op)
+
+    # split-phase form: the library runs the interior row blocks between begin and end
+    def _exchange_begin(self, level, x_ptr):
+        self._pending[level] = self._exchange(level, x_ptr, async_op=True)
+
+    def _exchange_end(self, level, x_ptr):
+        w = self._pending.pop(level, None)
+        if w is not None:
+            w.wait()
 
     # ---- setup
-    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=1024, max_levels=32, log=None):
+    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=1024, max_levels=32, log=None, overlap=True):
         comm, ctx = self.comm, self.ctx
         self._prepare_plan(0)
         A = self.A
@@ -266,7 +277,10 @@ class ShardedHierarchy:
             if log:
                 log(f"sharded level {len(self.plans) - 1}: local {nc_loc} rows (+{cplan.n_halo} halo), global {int(ncs.sum())}")
         self._build_tail(ktg, npass, tou, coarse_rows, log)
-        self.h.set_halo_exchange(self._exchange)
+        if overlap:
+            self.h.set_halo_exchange_split(self._exchange_begin, self._exchange_end)
+        else:
+            self.h.set_halo_exchange(self._exchange)
         return self
 
     def _build_tail(self, ktg, npass, tou, coarse_rows, log):

@@ -22,6 +22,7 @@ def main():
 
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     tail_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+    overlap = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -32,7 +33,7 @@ def main():
     A = ctx.poisson3d(N, lo, hi, local_cols=True)
     n_loc, n_ext = A.shape
     sh = mgd.ShardedHierarchy(ctx, A, mgd.poisson_plane_plan(N, world, rank), 0.6, 1, 1, comm)
-    sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100)
+    sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     n2 = N * N
     bg = orc.rand_rhs(N ** 3)
