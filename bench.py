@@ -248,6 +248,15 @@ def main():
     vbytes = h.vcycle_bytes
     log(f"V-cycle {ms_step:.3f} ms ({args.steps / elapsed:.2f} /s), algorithmic {vbytes / 1e9:.2f} GB/cycle = {vbytes / elapsed * args.steps / 1e9:.0f} GB/s")
 
+    # A/B inside the same process: the unfused one-kernel-per-step form of the same cycle
+    ctx.set_option("fuse", 0)
+    for _ in range(2):
+        h.vcycle(b, x)
+    ms_unfused = h.time_vcycle(b, x, reps=max(3, args.steps // 2))
+    ctx.set_option("fuse", 1)
+    h.vcycle(b, x)
+    log(f"unfused form of the same cycle: {ms_unfused:.3f} ms")
+
     # quality: residual reduction of one cycle and a preconditioned solve to 1e-10 (untimed)
     r0 = b.nrm2(); r1 = A.residual(x, b).nrm2()
     xsol = ctx.vec(n)
@@ -271,7 +280,8 @@ def main():
                      "ms_per_launch": ms_spmv,
                      "other_kernels": {"residual": {"ms": ms_res, "gbps": gbps(residual_bytes(n, nnz), ms_res)},
                                        "jacobi": {"ms": ms_jac, "gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
-                     "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9},
+                     "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9,
+                     "vcycle_ms_unfused_form": ms_unfused},
         "solve_check": {"one_cycle_residual_reduction": r1 / r0, "bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol,
                         "bicgstab_seconds": t_solve},
     }

@@ -20,6 +20,8 @@
 // No MFMA: arithmetic intensity is 0.13 flop/B; the bound is HBM (≈8 TB/s peak).
 #include "mgs_internal.hpp"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int RB = 256;         // rows per row block == threads per workgroup
@@ -225,6 +227,153 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
   }
 }
 
+// Fused V-cycle passes on the slice kernel (square, unsharded levels only):
+//   FUSE_PRE : from x = 0 with ν1 = 1:  x1 = wd∘b,  r = b − A·x1   (gathers wd[c]·b[c]; one pass instead
+//              of the (ωD⁻¹)b kernel + the residual kernel; bit-identical to the two-kernel form)
+//   FUSE_POST: coarse-grid correction + one Jacobi sweep:  x'' = x + Pe + wd∘(r − A·Pe), Pe_j = ec[agg_j]
+//              (r = b − Ax is the residual already computed before restriction, so b − A(x+Pe) = r − A·Pe;
+//              one pass instead of prolong-add + Jacobi; equal to the two-kernel form up to rounding)
+// wd = ω·dinv precomputed per level.
+template <int OP>
+__global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ wd, const double *__restrict__ bvec /*PRE: b, POST: r*/, const double *__restrict__ xin /*POST: x*/,
+    const int *__restrict__ agg, const double *__restrict__ ec, double *__restrict__ out /*PRE: r, POST: x''*/,
+    double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm) {
+  extern __shared__ double lds_raw[];
+  const int vb = map_block(bm, blockIdx.x);
+  if (vb < 0) return;
+  const int r0 = (bm.base + vb) * RB;
+  const int r1 = min(r0 + RB, n);
+  const int tid = threadIdx.x;
+  const int lo = rowptr[r0];
+  const int hi = rowptr[r1];
+  double *__restrict__ vals = lds_raw;
+  int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
+  const int row = r0 + tid;
+  const int start = lo & ~1;
+  int my_a = 0, my_e = 0;
+  double bi = 0.0, wi = 0.0, xi = 0.0, pei = 0.0;
+  if (row < r1) {
+    my_a = rowptr[row] - start; my_e = rowptr[row + 1] - start;
+    bi = bvec[row]; wi = wd[row];
+    if (OP == FUSE_POST) { xi = xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }
+  }
+  const int nch = (hi - start + 1) >> 1;
+#pragma unroll 4
+  for (int c = tid; c < nch; c += RB) {
+    const int k = start + 2 * c;
+    *reinterpret_cast<int2_t *>(cols + 2 * c) = *reinterpret_cast<const int2_t *>(col + k);
+    *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
+  }
+  __syncthreads();
+  if (row < r1) {
+    double s = 0.0;
+    for (int k = my_a; k < my_e; k += 8) {
+      double xv[8];
+      const int rem = my_e - k;
+      if (OP == FUSE_PRE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if (q < rem) { const int c = cols[k + q]; xv[q] = wd[c] * bvec[c]; } else xv[q] = 0.0; }
+      } else {
+        int av[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) av[q] = q < rem ? agg[cols[k + q]] : -1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+    }
+    if (OP == FUSE_PRE) { out[row] = bi - s; out2[row] = wi * bi; }
+    else out[row] = (xi + pei) + wi * (bi - s);
+  }
+}
+
+// Variant C: variant B software-pipelined over G consecutive row blocks per workgroup.  The slice of
+// row block i+1 is already in flight (registers) while the lanes gather x and sum row block i, so the
+// val/col stream never waits for the gather phase of its own workgroup.  Same arithmetic, same order.
+template <int OP, bool NT, int ITER, int G>
+__global__ __launch_bounds__(RB) void csr_rowblock_pipe_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
+    double *__restrict__ out, int cap, BlockMap bm, int nrb_total /*row blocks of the launched range*/) {
+  extern __shared__ double lds_raw[];
+  double *__restrict__ vals = lds_raw;
+  int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
+  const int sb = map_block(bm, blockIdx.x);      // super block index (G row blocks each)
+  if (sb < 0) return;
+  const int tid = threadIdx.x;
+  const int first = sb * G;
+  const int nblk = min(G, nrb_total - first);
+  int bnd[G + 1];
+#pragma unroll
+  for (int j = 0; j <= G; ++j) { const int r = min((bm.base + first + j) * RB, n); bnd[j] = rowptr[r]; }
+  double2_t rv[ITER]; int2_t rc[ITER];
+  auto issue = [&](int j) {
+    const int start = bnd[j] & ~1;
+    const int nch = (bnd[j + 1] - start + 1) >> 1;
+#pragma unroll
+    for (int q = 0; q < ITER; ++q) {
+      const int c = tid + q * RB;
+      if (c < nch) {
+        rc[q] = ld_stream<NT>(reinterpret_cast<const int2_t *>(col + start + 2 * c));
+        rv[q] = ld_stream<NT>(reinterpret_cast<const double2_t *>(val + start + 2 * c));
+      }
+    }
+  };
+  issue(0);
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    if (j >= nblk) break;
+    const int r0 = (bm.base + first + j) * RB, r1 = min(r0 + RB, n);
+    const int lo = bnd[j], hi = bnd[j + 1];
+    const int start = lo & ~1;
+    const int nch = (hi - start + 1) >> 1;
+    const int row = r0 + tid;
+    int my_a = 0, my_e = 0;
+    double bi = 0.0, di = 0.0, xi = 0.0;
+    if (row < r1) {
+      my_a = rowptr[row] - start; my_e = rowptr[row + 1] - start;
+      if (OP != MGS_OP_SPMV) bi = b[row];
+      if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
+    }
+#pragma unroll
+    for (int q = 0; q < ITER; ++q) {
+      const int c = tid + q * RB;
+      if (c < nch) {
+        *reinterpret_cast<double2_t *>(vals + 2 * c) = rv[q];
+        *reinterpret_cast<int2_t *>(cols + 2 * c) = rc[q];
+      }
+    }
+    __syncthreads();
+    if (j + 1 < nblk) issue(j + 1);
+    if (row < r1) {
+      double s = 0.0;
+      int k = my_a;
+      for (; k + 8 <= my_e; k += 8) {
+        double xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = x[cols[k + q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += vals[k + q] * xv[q];
+      }
+      {
+        double xv[8];
+        const int rem = my_e - k;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = q < rem ? x[cols[k + q]] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+      }
+      if (OP == MGS_OP_SPMV) out[row] = s;
+      else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
+      else out[row] = xi + (omega * di) * (bi - s);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
                             int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
                                                     [3]=#row blocks touching halo columns,[4]=min block without halo,[5]=max block without halo*/) {
@@ -327,6 +476,7 @@ int mgs_plan_csr(mgs_csr *A) {
       A->halo_split_ok = (h[3] == lo_cnt + hi_cnt) && (nblocks - lo_cnt - hi_cnt) > 0;
     }
   }
+  A->max_block_nnz = h[0];
   A->lds_cap = h[0] < LDS_CAP_MAX ? h[0] : LDS_CAP_MAX;
   if (A->lds_cap < 64) A->lds_cap = 64;
   return MGS_OK;
@@ -335,6 +485,34 @@ int mgs_plan_csr(mgs_csr *A) {
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,
                       double omega, double *out) {
   return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, (A->rows + RB - 1) / RB);
+}
+
+// fused passes (see csr_rowblock_fused_kernel); returns MGS_ERR_STATE when the level cannot use them
+int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
+                     const double *ec, double *out, double *out2) {
+  mgs_ctx *ctx = A->ctx;
+  if (A->rows == 0) return MGS_OK;
+  if (A->rows != A->cols || A->max_block_nnz > A->lds_cap || A->lds_cap <= 0) return MGS_ERR_STATE;
+  BlockMap bm;
+  bm.base = 0; bm.nblocks = (A->rows + RB - 1) / RB;
+  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
+  bm.chunk = (bm.nblocks + 7) / 8;
+  bm.D = 0; bm.S = 0; bm.P = 0;
+  int per_xcd = bm.chunk;
+  if (bm.remap && ctx->opt_strip != 0) {
+    const int D = (A->far_band + RB - 1) / RB;
+    if (D >= 256 && bm.chunk >= 2 * D) {
+      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
+      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+    }
+  }
+  dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  const int cap = A->lds_cap;
+  const size_t lds = (size_t)(cap + 2) * 12 + 16;
+  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm);
+  else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
 }
 
 // the same kernels on the row blocks [blk_lo, blk_hi) only (interior / boundary split of a row shard)
@@ -359,14 +537,44 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
       per_xcd = strips * bm.P * bm.S;
     }
   }
-  dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   int cap = ctx->opt_spmv_variant == 1 ? -1 : A->lds_cap;
+  if (ctx->opt_spmv_variant == 6 && A->max_block_nnz <= 2048 && A->max_block_nnz == A->lds_cap) {
+    // pipelined variant: G row blocks per workgroup; block map over super blocks
+    constexpr int G = 4;
+    const int nrb = bm.nblocks;
+    BlockMap sm = bm;
+    sm.nblocks = (nrb + G - 1) / G;
+    sm.remap = ctx->opt_xcd_remap && sm.nblocks >= 64;
+    sm.chunk = (sm.nblocks + 7) / 8;
+    sm.D = 0; sm.S = 0; sm.P = 0;
+    int per = sm.chunk;
+    if (sm.remap && ctx->opt_strip != 0) {
+      const int D = ((A->far_band + RB - 1) / RB + G - 1) / G;
+      if (D >= 64 && sm.chunk >= 2 * D) {
+        sm.D = D; sm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / G) : 16; sm.P = (sm.chunk + D - 1) / D;
+        per = ((D + sm.S - 1) / sm.S) * sm.P * sm.S;
+      }
+    }
+    // base stays in row-block units inside the kernel: bm.base + first + j
+    dim3 g(sm.remap ? per * 8 : sm.nblocks);
+    const size_t lds = (size_t)(cap + 2) * 12 + 16;
+    hipStream_t st = ctx->stream;
+    const bool ntp = ctx->opt_nontemporal != 0;
+#define P_(O, NTV) hipLaunchKernelGGL((csr_rowblock_pipe_kernel<O, NTV, 4, G>), g, dim3(RB), lds, st, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, sm, nrb)
+    if (op == MGS_OP_SPMV) { if (ntp) P_(MGS_OP_SPMV, true); else P_(MGS_OP_SPMV, false); }
+    else if (op == MGS_OP_RESIDUAL) { if (ntp) P_(MGS_OP_RESIDUAL, true); else P_(MGS_OP_RESIDUAL, false); }
+    else { if (ntp) P_(MGS_OP_JACOBI, true); else P_(MGS_OP_JACOBI, false); }
+#undef P_
+    MGS_HIP(ctx, hipGetLastError());
+    return MGS_OK;
+  }
+  dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   size_t lds = sizeof(double) * (size_t)(cap > 0 ? cap : 1);
   // lanes per row of the long-row path: next power of two ≥ mean row length, in [4,64]
   double mean = A->rows ? (double)A->nnz / A->rows : 1.0;
   int lanes = 4;
   while (lanes < 64 && lanes < mean) lanes <<= 1;
-  const bool nt = ctx->opt_nontemporal != 0;
+  const bool nt = ctx->opt_nontemporal > 0;
   // variants: 0 auto, 1 forced sub-wavefront rows, 2/3/4 = products-in-LDS with 1/2/4 entries per lane, 5 = slice-in-LDS
   int chunk_elems = 0;
   switch (ctx->opt_spmv_variant) { case 2: chunk_elems = 1; break; case 3: chunk_elems = 2; break; case 4: chunk_elems = 4; break; default: chunk_elems = 0; }

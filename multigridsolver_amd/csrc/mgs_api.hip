@@ -61,6 +61,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "spmv_variant") ctx->opt_spmv_variant = value;
   else if (k == "graph") ctx->opt_graph = value;
   else if (k == "strip") ctx->opt_strip = value;
+  else if (k == "fuse") ctx->opt_fuse = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
 }
@@ -279,7 +280,7 @@ static int level_init(mgs_hier *h, mgs_level &L, const mgs_csr *A, bool own) {
 static void level_free(mgs_level &L) {
   if (L.own_A && L.A) mgs_csr_destroy(const_cast<mgs_csr *>(L.A));
   if (L.T) mgs_xfer_destroy(L.T);
-  mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x);
+  mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x); mgs_vec_destroy(L.wd);
   L = mgs_level();
 }
 static void drop_graph(mgs_hier *h) {
@@ -412,17 +413,22 @@ int mgs_hier_finalize(mgs_hier *h) {
 
 int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
   // algorithmic bytes of the kernels one zero-guess cycle actually launches.
-  // Level 0 starts from x = 0 and so does every coarse level: the first pre-sweep is the
-  // 24n-byte (ωD⁻¹)b kernel, not a Jacobi pass.
+  // Every level starts from x = 0: the first pre-sweep is the 24n-byte (ωD⁻¹)b kernel, not a
+  // Jacobi pass.  Fused form (V(1,1), square level): pass A reads the matrix, wd, b and writes r, x1;
+  // pass B reads the matrix, r, x1, wd, agg, e_c and writes x.
   int64_t tot = 0;
   const int L = (int)h->lev.size();
   for (int l = 0; l < L - 1; ++l) {
     const mgs_level &lv = h->lev[l];
     int64_t n = lv.A->rows, nnz = lv.A->nnz, nc = h->lev[l + 1].A->rows, nnzP = lv.T ? lv.T->nnz : 0;
     const int64_t jac = 12 * nnz + 36 * n + 4, res = 12 * nnz + 28 * n + 4;
+    const int64_t restr = 4 * (nc + 1) + 12 * nnzP + 8 * nc;
+    const bool fused = h->ctx->opt_fuse && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && lv.T && lv.T->aggregation &&
+                       lv.A->rows == lv.A->cols && lv.A->max_block_nnz <= lv.A->lds_cap;
+    if (fused) { tot += (12 * nnz + 36 * n + 4) + restr + (12 * nnz + 40 * n + 8 * nc + 4); continue; }
     if (h->nu1 > 0) tot += 24 * n + (int64_t)(h->nu1 - 1) * jac + res;   // shortcut + sweeps + residual
     // ν1 = 0: r = b, no residual pass
-    tot += 4 * (nc + 1) + 12 * nnzP + 8 * nc;                              // restriction
+    tot += restr;
     tot += (h->nu1 > 0 ? 20 * n : 12 * n) + 8 * nc;                        // prolong-add / prolong
     tot += (int64_t)h->nu2 * jac;
   }
@@ -477,6 +483,19 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     return k_dense_gemv(ctx, h->nc, h->inv, b, x);
   }
   mgs_level &C = h->lev[l + 1];
+  // ---- fused form (square unsharded level, aggregation P, V(1,1) from x = 0): two matrix passes,
+  //      no separate (ωD⁻¹)b / prolong-add kernels
+  const bool can_fuse = ctx->opt_fuse && zero_guess && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && L.wd &&
+                        L.wd_omega == h->omega && L.T->aggregation && L.A->rows == L.A->cols &&
+                        L.A->max_block_nnz <= L.A->lds_cap && L.A->lds_cap > 0;
+  if (can_fuse) {
+    // x1 = wd∘b (into tmp), r = b − A·x1
+    MGS_TRY(mgs_launch_fused(L.A, FUSE_PRE, L.wd->d, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));
+    MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
+    MGS_TRY(cycle_level(h, l + 1, C.b->d, C.x->d, true));
+    // x = x1 + Pe + wd∘(r − A·Pe)
+    return mgs_launch_fused(L.A, FUSE_POST, L.wd->d, L.r->d, L.tmp->d, L.T->agg, C.x->d, x, nullptr);
+  }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
   int swaps = h->nu2 + (zero_guess ? (h->nu1 > 0 ? h->nu1 - 1 : 0) : h->nu1);
   double *cur = x, *alt = L.tmp->d;
@@ -511,11 +530,25 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   return MGS_OK;
 }
 
+// wd = ω·dinv of every level that can run the fused passes; allocated and filled outside any stream capture
+static int prepare_fused(mgs_hier *h) {
+  mgs_ctx *ctx = h->ctx;
+  if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || h->halo || h->halo_begin) return MGS_OK;
+  for (size_t l = 0; l + 1 < h->lev.size(); ++l) {
+    mgs_level &L = h->lev[l];
+    if (!L.T || !L.T->aggregation || L.A->rows != L.A->cols) continue;
+    if (!L.wd) MGS_TRY(mgs_vec_create(ctx, L.n, &L.wd));
+    if (L.wd_omega != h->omega) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
+  }
+  return MGS_OK;
+}
+
 extern "C" {
 
 int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   mgs_ctx *ctx = h->ctx;
   MGS_CHECK(ctx, h->finalized, MGS_ERR_STATE, "mgs_vcycle: call mgs_hier_finalize first");
+  MGS_TRY(prepare_fused(h));
   mgs_level &L0 = h->lev[0];
   MGS_CHECK(ctx, b->n >= L0.n && x->n >= L0.n, MGS_ERR_INVALID, "mgs_vcycle: vectors shorter than the operator (%d rows)", L0.n);
   MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
@@ -525,6 +558,8 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
   const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
+  if (h->graph && h->graph_fuse != ctx->opt_fuse) drop_graph(h);
+  h->graph_fuse = ctx->opt_fuse;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {

@@ -24,7 +24,8 @@ struct mgs_ctx {
   int n_cu = 256;
   // options
   int opt_xcd_remap = 1;
-  int opt_nontemporal = 1;
+  int opt_nontemporal = 0;  // non-temporal loads of val/col (measured: no gain with the slice kernel)
+  int opt_fuse = 1;         // fused V-cycle passes on square levels
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
@@ -45,7 +46,8 @@ struct mgs_csr {
   int far_band = 0;  // max |col - row| over owned columns
   int halo_lo_blocks = 0, halo_hi_blocks = 0;  // leading / trailing row blocks that read halo columns
   bool halo_split_ok = false;                  // no other block does → interior rows can overlap the exchange
-  int lds_cap = 0;  // products staged per block (doubles)
+  int lds_cap = 0;  // entries staged per block
+  int max_block_nnz = 0;
 };
 
 struct mgs_vec {
@@ -75,6 +77,8 @@ struct mgs_level {
   int n = 0;              // owned rows
   int n_ext = 0;          // owned + halo
   mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
+  mgs_vec *wd = nullptr;       // ω·dinv (fused passes)
+  double wd_omega = 0.0;       // ω that wd was built with
   mgs_vec *b = nullptr, *x = nullptr;  // coarse-level rhs / solution (levels >= 1)
 };
 
@@ -97,6 +101,7 @@ struct mgs_hier {
   const double *graph_b = nullptr;
   double *graph_x = nullptr;
   int graph_zero = -1;
+  int graph_fuse = -1;
 };
 
 // ------------------------------------------------------------------ error plumbing
@@ -124,7 +129,9 @@ int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...);
 
 // ------------------------------------------------------------------ kernel launchers
 // (kernels_spmv.hip)
-enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2 };
+enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2, FUSE_PRE = 3, FUSE_POST = 4 };
+int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
+                     const double *ec, double *out, double *out2);
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b,
                       const double *dinv, double omega, double *out);
 int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b,

@@ -255,6 +255,15 @@ def test_full_multilevel_solve(ctx, mg, orc):
     x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, b, h, 500, 1e-10)
     assert st == 0 and tol < 1e-10 and it < 100, (st, it, tol)
     assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10
+    # fused passes ((ωD⁻¹)b+residual, prolong+Jacobi) vs the one-kernel-per-step form: equal to rounding,
+    # both within 1e-10 of the oracle
+    ctx.set_option("fuse", 0)
+    try:
+        y_unfused = h.vcycle(b).numpy()
+    finally:
+        ctx.set_option("fuse", 1)
+    assert rel(y_unfused, ho.vcycle(b_np)) <= 1e-10
+    assert rel(h.vcycle(b).numpy(), y_unfused) <= 1e-13
     # graph replay and eager launches agree bit for bit
     ctx.set_option("graph", 0)
     try:
