@@ -199,7 +199,7 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if os.environ.get("MGS_DIST_SHARE_GPU") else local_rank)
     if world > 1:
         from multigridsolver_amd import dist as mgdist
         return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes)

@@ -17,6 +17,7 @@ torch.distributed is plumbing: backend "nccl" (= RCCL over xGMI) moves device bu
 backend "gloo" (CPU tests, or several ranks sharing one GPU) stages through host memory.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -367,7 +368,12 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes):
 
     from . import Context, OP_SPMV
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        # MGS_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the
+        # real multi-GPU run uses nccl (= RCCL over xGMI)
+        dist.init_process_group(backend=os.environ.get("MGS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
+    if os.environ.get("MGS_DIST_SHARE_GPU"):
+        local_rank = 0
+        torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = Context(local_rank, stream.cuda_stream)
