@@ -16,9 +16,10 @@ A = ctx.poisson3d(N)
 h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 1024, 32).finalize()
 x = ctx.vec(n).rand(seed=1); b = ctx.vec(n).rand(seed=0); y = ctx.vec(n); dinv = A.diag_inv()
 ctx.set_option("graph", 0)   # eager launches so every kernel shows up as its own dispatch
-# calibration: axpby_kernel y = 2x + 3y reads 16n bytes and writes 8n bytes with 8-byte lanes
+# calibration: axpbypcz_kernel z = 2x + 3b + 0.5z reads 24n bytes and writes 8n bytes with 8-byte lanes
+# (a kernel the V-cycle itself never launches, so every dispatch of it is a calibration launch)
 for _ in range(3):
-    mg.lib().mgs_axpby(2.0, x.h, 3.0, y.h)
+    mg.lib().mgs_axpbypcz(2.0, x.h, 3.0, b.h, 0.5, y.h)
 for _ in range(reps):
     A.spmv(x, y)
 for _ in range(reps):

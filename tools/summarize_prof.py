@@ -15,8 +15,9 @@ tag = sys.argv[1]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n = N ** 3
 nnz = 7 * n - 6 * N * N
-ALG = {"spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
-       "axpby(calibration)": 24 * n}
+nc1 = None
+ALG = {"fused_pre": 12 * nnz + 36 * n + 4, "fused_post": 12 * nnz + 40 * n + 4, "spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
+       "axpby(calibration)": 32 * n}
 
 
 def newest(pattern):
@@ -33,7 +34,9 @@ def classify(name):
     for pre in ("csr_rowblock_kernel<", "csr_rowblock_slice_kernel<"):
         if s.startswith(pre):
             return {"0": "spmv", "1": "residual", "2": "jacobi"}.get(s[len(pre)], None)
-    if s.startswith("axpby_kernel"): return "axpby(calibration)"
+    if s.startswith("csr_rowblock_fused_kernel<3"): return "fused_pre"
+    if s.startswith("csr_rowblock_fused_kernel<4"): return "fused_post"
+    if s.startswith("axpbypcz_kernel"): return "axpby(calibration)"
     return None
 
 
@@ -56,11 +59,11 @@ def pmc(sub, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-# calibration (MI355X_MICROARCH.md §HBM): axpby y=2x+3y reads 16n bytes, writes 8n bytes
-cal_read = 16 * n / (fetch["axpby(calibration)"] * 1024)
+# calibration (MI355X_MICROARCH.md §HBM): z = 2x+3b+0.5z reads 24n bytes, writes 8n bytes
+cal_read = 24 * n / (fetch["axpby(calibration)"] * 1024)
 cal_write = 8 * n / (write["axpby(calibration)"] * 1024)
 rows = []
-for k in ["spmv", "residual", "jacobi", "axpby(calibration)"]:
+for k in [k for k in ["spmv", "residual", "jacobi", "fused_pre", "fused_post", "axpby(calibration)"] if k in fine and k in fetch and k in write]:
     d = sorted(fine[k]); med = d[len(d) // 2]; avg = sum(d) / len(d)
     fb = fetch[k] * 1024 * cal_read; wb = write[k] * 1024 * cal_write
     rows.append({"kernel": k, "launches": len(d), "avg_us": avg / 1e3, "median_us": med / 1e3, "algorithmic_bytes": ALG[k],
