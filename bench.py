@@ -218,6 +218,8 @@ def main():
     t_setup = time.perf_counter() - t0
     levels = [h.level_shape(l) for l in range(h.nlev)]
     log(f"hierarchy built on device in {t_setup:.2f}s: " + " > ".join(f"{r}r/{z}nnz" for r, z in levels))
+    plans = [h.level_A(l).plan_info() for l in range(h.nlev)]
+    log("level plans (max_block_nnz/max_row/far_band/lds): " + " ".join(f"{p['max_block_nnz']}/{p['max_row_len']}/{p['far_band']}/{p['lds_bytes']}" for p in plans[:5]))
 
     b = ctx.vec(n).rand(seed=0)
     x = ctx.vec(n)

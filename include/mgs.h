@@ -242,6 +242,11 @@ int mgs_time_kernel(const mgs_csr *A, int op, const mgs_vec *x, const mgs_vec *b
                     const mgs_vec *dinv, mgs_vec *out, int reps, double *ms);
 /* Time `reps` V-cycles with hipEvents on the context's stream.                        */
 int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double *ms);
+/* launch plan of a matrix (diagnostics): out[0]=max entries of a 256-row block, [1]=max row
+ * length, [2]=far band (max |col−row| over owned columns), [3]=LDS bytes per workgroup of the
+ * row-block kernel, [4]=leading and [5]=trailing row blocks that read halo columns, [6]=1 if the
+ * interior/boundary split is usable, [7]=1 if some block takes the long-row path.            */
+int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
 /* kernel-variant knobs for A/B measurements (0 = default).  key: "spmv_variant",
  * "xcd_remap", "nontemporal", "graph".                                                */
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);

@@ -130,6 +130,11 @@ class Csr:
     def nnz(self):
         n = C.c_int64(); lib().mgs_csr_shape(self.h, None, None, C.byref(n)); return n.value
 
+    def plan_info(self):
+        out = (C.c_int64 * 8)(); lib().mgs_csr_plan_info(self.h, out)
+        keys = ["max_block_nnz", "max_row_len", "far_band", "lds_bytes", "halo_lo_blocks", "halo_hi_blocks", "halo_split_ok", "has_long_row_blocks"]
+        return dict(zip(keys, [int(v) for v in out]))
+
     def download(self):
         rows, _ = self.shape; nnz = self.nnz
         rp = np.empty(rows + 1, dtype=np.int32); ci = np.empty(max(nnz, 1), dtype=np.int32); v = np.empty(max(nnz, 1))

@@ -54,9 +54,12 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
 // p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
 struct BlockMap { int nblocks, chunk, remap, D, S, P, base; };   // base: first row block of the launched range
+__device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx);
 __device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
   if (!m.remap) return bid < m.nblocks ? bid : -1;
-  const int xcd = bid & 7, idx = bid >> 3;
+  return map_block_xi(m, bid & 7, bid >> 3);
+}
+__device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx) {
   int lb = idx;
   if (m.D > 0) {
     const int ps = m.P * m.S;
@@ -290,6 +293,62 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   }
 }
 
+// Variant D: variant B with ONE WAVE per workgroup (64 rows, ~5 KB of LDS).  No workgroup barrier at
+// all — a wave's LDS writes are ordered before its own reads — so every wave streams, gathers and
+// stores at its own pace and the CU always has waves in each phase.  Four consecutive 64-row groups of
+// one 256-row block map to the same XCD (locality as in variant B).
+template <int OP>
+__global__ __launch_bounds__(64) void csr_wave_slice_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
+    double *__restrict__ out, int cap, BlockMap bm) {
+  extern __shared__ double lds_raw[];
+  const int bid = blockIdx.x;
+  int vb, sub;
+  if (bm.remap) { const int idx = bid >> 3; vb = map_block_xi(bm, bid & 7, idx >> 2); sub = idx & 3; }
+  else { vb = (bid >> 2) < bm.nblocks ? (bid >> 2) : -1; sub = bid & 3; }
+  if (vb < 0) return;
+  const int r0 = (bm.base + vb) * RB + sub * 64;
+  if (r0 >= n) return;
+  const int r1 = min(r0 + 64, n);
+  const int tid = threadIdx.x;
+  const int lo = rowptr[r0];
+  const int hi = rowptr[r1];
+  double *__restrict__ vals = lds_raw;
+  int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
+  const int row = r0 + tid;
+  const int start = lo & ~1;
+  int my_a = 0, my_e = 0;
+  double bi = 0.0, di = 0.0, xi = 0.0;
+  if (row < r1) {
+    my_a = rowptr[row] - start; my_e = rowptr[row + 1] - start;
+    if (OP != MGS_OP_SPMV) bi = b[row];
+    if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
+  }
+  const int nch = (hi - start + 1) >> 1;
+#pragma unroll 4
+  for (int c = tid; c < nch; c += 64) {
+    const int k = start + 2 * c;
+    *reinterpret_cast<int2_t *>(cols + 2 * c) = *reinterpret_cast<const int2_t *>(col + k);
+    *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
+  }
+  __syncthreads();   // single-wave workgroup: lowers to a wait on the wave's own LDS writes
+  if (row < r1) {
+    double s = 0.0;
+    for (int k = my_a; k < my_e; k += 8) {
+      double xv[8];
+      const int rem = my_e - k;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = q < rem ? x[cols[k + q]] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+    }
+    if (OP == MGS_OP_SPMV) out[row] = s;
+    else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
+    else out[row] = xi + (omega * di) * (bi - s);
+  }
+}
+
 // Variant C: variant B software-pipelined over G consecutive row blocks per workgroup.  The slice of
 // row block i+1 is already in flight (registers) while the lanes gather x and sum row block i, so the
 // val/col stream never waits for the gather phase of its own workgroup.  Same arithmetic, same order.
@@ -383,6 +442,7 @@ __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__
     bool halo = false;
     int r0 = vb * RB, r1 = min(r0 + RB, n);
     mx = rowptr[r1] - rowptr[r0];
+    for (int q = r0; q < r1; q += 64) atomicMax(&out[6], rowptr[min(q + 64, r1)] - rowptr[q]);
     for (int r = r0; r < r1; ++r) {
       const int a = rowptr[r], e = rowptr[r + 1];
       mr = max(mr, e - a);
@@ -456,11 +516,11 @@ int mgs_plan_csr(mgs_csr *A) {
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
   int *d = nullptr;
-  MGS_TRY(mgs_dev_alloc(ctx, &d, 6));
-  const int init[6] = {0, 0, 0, 0, 0x7fffffff, -1};
+  MGS_TRY(mgs_dev_alloc(ctx, &d, 7));
+  const int init[7] = {0, 0, 0, 0, 0x7fffffff, -1, 0};
   MGS_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, A->col, nblocks, d);
-  int h[6] = {0, 0, 0, 0, 0, 0};
+  int h[7] = {0, 0, 0, 0, 0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_HIP(ctx, hipFree(d));
@@ -477,6 +537,7 @@ int mgs_plan_csr(mgs_csr *A) {
     }
   }
   A->max_block_nnz = h[0];
+  A->max_wave_nnz = h[6];
   A->lds_cap = h[0] < LDS_CAP_MAX ? h[0] : LDS_CAP_MAX;
   if (A->lds_cap < 64) A->lds_cap = 64;
   return MGS_OK;
@@ -565,6 +626,17 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
     else if (op == MGS_OP_RESIDUAL) { if (ntp) P_(MGS_OP_RESIDUAL, true); else P_(MGS_OP_RESIDUAL, false); }
     else { if (ntp) P_(MGS_OP_JACOBI, true); else P_(MGS_OP_JACOBI, false); }
 #undef P_
+    MGS_HIP(ctx, hipGetLastError());
+    return MGS_OK;
+  }
+  if (ctx->opt_spmv_variant == 7 && A->max_wave_nnz <= 4096) {
+    const int capw = A->max_wave_nnz;
+    dim3 g((bm.remap ? per_xcd * 8 : bm.nblocks) * 4);
+    const size_t ldsw = (size_t)(capw + 2) * 12 + 16;
+    hipStream_t st = ctx->stream;
+#define W_(O) hipLaunchKernelGGL((csr_wave_slice_kernel<O>), g, dim3(64), ldsw, st, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, capw, bm)
+    if (op == MGS_OP_SPMV) W_(MGS_OP_SPMV); else if (op == MGS_OP_RESIDUAL) W_(MGS_OP_RESIDUAL); else W_(MGS_OP_JACOBI);
+#undef W_
     MGS_HIP(ctx, hipGetLastError());
     return MGS_OK;
   }

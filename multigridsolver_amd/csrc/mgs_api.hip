@@ -124,6 +124,11 @@ int mgs_csr_device_ptrs(const mgs_csr *A, void **rowptr, void **col, void **val)
   if (rowptr) *rowptr = A->rowptr; if (col) *col = A->col; if (val) *val = A->val;
   return MGS_OK;
 }
+int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]) {
+  out[0] = A->max_block_nnz; out[1] = A->max_row_len; out[2] = A->far_band; out[3] = (int64_t)(A->lds_cap + 2) * 12 + 16;
+  out[4] = A->halo_lo_blocks; out[5] = A->halo_hi_blocks; out[6] = A->halo_split_ok ? 1 : 0; out[7] = A->max_block_nnz > A->lds_cap ? 1 : 0;
+  return MGS_OK;
+}
 int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
   if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }

@@ -48,6 +48,7 @@ struct mgs_csr {
   bool halo_split_ok = false;                  // no other block does → interior rows can overlap the exchange
   int lds_cap = 0;  // entries staged per block
   int max_block_nnz = 0;
+  int max_wave_nnz = 0;   // max entries of a 64-row group
 };
 
 struct mgs_vec {

@@ -201,6 +201,7 @@ class ShardedHierarchy:
         self.tail = None
         self._views, self._bufs, self._keep, self._xc, self._pending = {}, {}, [], {}, {}
         self.n_exchanges = 0
+        self.overlap_min_rows = 1_000_000
 
     # ---- device helpers
     def _view(self, ptr, n, typestr="<f8"):
@@ -241,7 +242,10 @@ class ShardedHierarchy:
 
     # split-phase form: the library runs the interior row blocks between begin and end
     def _exchange_begin(self, level, x_ptr):
-        self._pending[level] = self._exchange(level, x_ptr, async_op=True)
+        # asynchronous work objects cost ~25 us more host time than the blocking form (measured,
+        # tools/exchange_overhead.py): worth it only where the interior kernel is long enough to hide it
+        big = self.plans[level].n_loc >= self.overlap_min_rows
+        self._pending[level] = self._exchange(level, x_ptr, async_op=big)
 
     def _exchange_end(self, level, x_ptr):
         w = self._pending.pop(level, None)

@@ -33,6 +33,7 @@ def main():
     A = ctx.poisson3d(N, lo, hi, local_cols=True)
     n_loc, n_ext = A.shape
     sh = mgd.ShardedHierarchy(ctx, A, mgd.poisson_plane_plan(N, world, rank), 0.6, 1, 1, comm)
+    sh.overlap_min_rows = 0   # exercise the asynchronous form on every level
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     n2 = N * N

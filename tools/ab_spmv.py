@@ -17,7 +17,7 @@ A = ctx.poisson3d(N)
 nnz = A.nnz
 x = ctx.vec(n).rand(seed=1); y = ctx.vec(n); b = ctx.vec(n).rand(seed=2); dinv = A.diag_inv()
 byts = 12 * nnz + 20 * n + 4
-variants = [(3, 0, 1), (5, 0, 1), (5, 64, 1), (5, 64, 0), (6, 0, 1), (6, 64, 1), (6, 64, 0), (6, 128, 1)]
+variants = [(5, 0, 0), (5, 64, 0), (5, 128, 0), (7, 0, 0), (7, 64, 0), (7, 128, 0), (7, 32, 0)]
 ref = None
 times = {k: [] for k in variants}
 for rnd in range(4):
@@ -33,7 +33,7 @@ print(f"grid {N}^3  algorithmic bytes {byts/1e9:.3f} GB")
 print("chunk strip nt   median_ms   min_ms   GB/s(median)  frac_of_8TB/s")
 for (v, s, nt), t in sorted(times.items(), key=lambda kv: np.median(kv[1])):
     med, mn = float(np.median(t)), float(min(t))
-    print(f"{ {2:1,3:2,4:4,5:0,6:-1}[v]:5d} {s:5d} {nt:2d} {med:10.3f} {mn:8.3f} {byts/med/1e6:12.0f} {byts/med/1e6/8000:10.3f}")
+    print(f"{ {2:1,3:2,4:4,5:0,6:-1,7:-7}[v]:5d} {s:5d} {nt:2d} {med:10.3f} {mn:8.3f} {byts/med/1e6:12.0f} {byts/med/1e6/8000:10.3f}")
 # jacobi / residual with the default (auto) settings
 ctx.set_option("spmv_variant", 0); ctx.set_option("strip", -1); ctx.set_option("nontemporal", 1)
 for name, op, bb in (("spmv", mg.OP_SPMV, 12 * nnz + 20 * n), ("residual", mg.OP_RESIDUAL, 12 * nnz + 28 * n), ("jacobi", mg.OP_JACOBI, 12 * nnz + 36 * n)):
