@@ -163,7 +163,7 @@ template <int OP, bool NT, int LANES>
 __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
-    double *__restrict__ out, int cap, BlockMap bm) {
+    double *__restrict__ out, int cap, BlockMap bm, int seq_overflow) {
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
@@ -217,6 +217,15 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
       else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
       else out[row] = xi + (omega * di) * (bi - s);
     }
+  } else if (seq_overflow) {
+    // heavier-than-budget block of short rows: lane t walks row t straight from global memory, same
+    // ascending order (bit-identical to the staged path)
+    const int row = r0 + tid;
+    if (row < r1) {
+      double s = 0.0;
+      for (int k = rowptr[row], e = rowptr[row + 1]; k < e; ++k) s += val[k] * x[col[k]];
+      epilogue<OP>(row, s, x, b, dinv, omega, out);
+    }
   } else {
     const int sub = tid / LANES, lane = tid % LANES;
     for (int row = r0 + sub; row < r1; row += RB / LANES) {
@@ -237,6 +246,30 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 //              (r = b − Ax is the residual already computed before restriction, so b − A(x+Pe) = r − A·Pe;
 //              one pass instead of prolong-add + Jacobi; equal to the two-kernel form up to rounding)
 // wd = ω·dinv precomputed per level.
+template <int OP, bool STAGED>
+__device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc, const int *__restrict__ csrc, int a, int e,
+                                                const double *__restrict__ wd, const double *__restrict__ bvec,
+                                                const int *__restrict__ agg, const double *__restrict__ ec) {
+  double s = 0.0;
+  for (int k = a; k < e; k += 8) {
+    double xv[8];
+    const int rem = e - k;
+    if (OP == FUSE_PRE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { if (q < rem) { const int c = csrc[k + q]; xv[q] = wd[c] * bvec[c]; } else xv[q] = 0.0; }
+    } else {
+      int av[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) av[q] = q < rem ? agg[csrc[k + q]] : -1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < rem) s += vsrc[k + q] * xv[q];
+  }
+  return s;
+}
+
 template <int OP>
 __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
@@ -255,39 +288,27 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
   const int row = r0 + tid;
   const int start = lo & ~1;
-  int my_a = 0, my_e = 0;
+  const bool staged = hi - lo <= cap;      // block-uniform; the few heavier blocks read their rows from global memory
+  int ga = 0, ge = 0;
   double bi = 0.0, wi = 0.0, xi = 0.0, pei = 0.0;
   if (row < r1) {
-    my_a = rowptr[row] - start; my_e = rowptr[row + 1] - start;
+    ga = rowptr[row]; ge = rowptr[row + 1];
     bi = bvec[row]; wi = wd[row];
     if (OP == FUSE_POST) { xi = xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }
   }
-  const int nch = (hi - start + 1) >> 1;
+  if (staged) {
+    const int nch = (hi - start + 1) >> 1;
 #pragma unroll 4
-  for (int c = tid; c < nch; c += RB) {
-    const int k = start + 2 * c;
-    *reinterpret_cast<int2_t *>(cols + 2 * c) = *reinterpret_cast<const int2_t *>(col + k);
-    *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
-  }
-  __syncthreads();
-  if (row < r1) {
-    double s = 0.0;
-    for (int k = my_a; k < my_e; k += 8) {
-      double xv[8];
-      const int rem = my_e - k;
-      if (OP == FUSE_PRE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { if (q < rem) { const int c = cols[k + q]; xv[q] = wd[c] * bvec[c]; } else xv[q] = 0.0; }
-      } else {
-        int av[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) av[q] = q < rem ? agg[cols[k + q]] : -1;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+    for (int c = tid; c < nch; c += RB) {
+      const int k = start + 2 * c;
+      *reinterpret_cast<int2_t *>(cols + 2 * c) = *reinterpret_cast<const int2_t *>(col + k);
+      *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
     }
+    __syncthreads();
+  }
+  if (row < r1) {
+    const double s = staged ? fused_row_sum<OP, true>(vals, cols, ga - start, ge - start, wd, bvec, agg, ec)
+                            : fused_row_sum<OP, false>(val, col, ga, ge, wd, bvec, agg, ec);
     if (OP == FUSE_PRE) { out[row] = bi - s; out2[row] = wi * bi; }
     else out[row] = (xi + pei) + wi * (bi - s);
   }
@@ -433,6 +454,18 @@ __global__ __launch_bounds__(RB) void csr_rowblock_pipe_kernel(
   }
 }
 
+// number of row blocks whose entry count exceeds each of 4 candidate LDS budgets
+__global__ void plan_count_kernel(int n, const int *__restrict__ rowptr, int nblocks, int c0, int c1, int c2, int c3, int *__restrict__ out) {
+  int vb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vb >= nblocks) return;
+  int r0 = vb * RB, r1 = min(r0 + RB, n);
+  int cnt = rowptr[r1] - rowptr[r0];
+  if (cnt > c0) atomicAdd(&out[0], 1);
+  if (cnt > c1) atomicAdd(&out[1], 1);
+  if (cnt > c2) atomicAdd(&out[2], 1);
+  if (cnt > c3) atomicAdd(&out[3], 1);
+}
+
 __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
                             int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
                                                     [3]=#row blocks touching halo columns,[4]=min block without halo,[5]=max block without halo*/) {
@@ -485,7 +518,7 @@ int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const 
   const size_t lds = (size_t)(cap > 0 ? cap + 2 : 2) * 12 + 16;
 #define L_(LN)                                                                                             \
   hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN>), grid, dim3(RB), lds, s, A->rows, A->rowptr, \
-                     A->col, A->val, x, b, dinv, omega, out, cap, bm)
+                     A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0)
   switch (lanes) {
     case 4: L_(4); break;
     case 8: L_(8); break;
@@ -540,6 +573,23 @@ int mgs_plan_csr(mgs_csr *A) {
   A->max_wave_nnz = h[6];
   A->lds_cap = h[0] < LDS_CAP_MAX ? h[0] : LDS_CAP_MAX;
   if (A->lds_cap < 64) A->lds_cap = 64;
+  // LDS budget per workgroup sets the occupancy.  A handful of heavy row blocks (G0 fringes, irregular
+  // aggregates on coarse levels) must not size it for everyone: take the smallest budget that still
+  // stages ≥ 98.5 % of the row blocks; the rest run their rows from global memory (block-uniform branch).
+  const double mean = (double)A->nnz / nblocks;
+  if (nblocks >= 64 && (double)A->lds_cap > 1.12 * mean) {
+    int cand[4] = {(int)(1.06 * mean) + 8, (int)(1.12 * mean) + 8, (int)(1.25 * mean) + 8, (int)(1.5 * mean) + 8};
+    int *dc = nullptr;
+    MGS_TRY(mgs_dev_alloc(ctx, &dc, 4));
+    MGS_HIP(ctx, hipMemsetAsync(dc, 0, 4 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(plan_count_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, nblocks, cand[0], cand[1], cand[2], cand[3], dc);
+    int over[4] = {0, 0, 0, 0};
+    MGS_HIP(ctx, hipMemcpyAsync(over, dc, sizeof over, hipMemcpyDeviceToHost, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MGS_HIP(ctx, hipFree(dc));
+    for (int q = 0; q < 4; ++q)
+      if (cand[q] < A->lds_cap && over[q] <= 0.015 * nblocks) { A->lds_cap = cand[q]; break; }
+  }
   return MGS_OK;
 }
 
@@ -553,7 +603,7 @@ int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double
                      const double *ec, double *out, double *out2) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0) return MGS_OK;
-  if (A->rows != A->cols || A->max_block_nnz > A->lds_cap || A->lds_cap <= 0) return MGS_ERR_STATE;
+  if (A->rows != A->cols || A->lds_cap <= 0) return MGS_ERR_STATE;
   BlockMap bm;
   bm.base = 0; bm.nblocks = (A->rows + RB - 1) / RB;
   bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;

@@ -429,7 +429,7 @@ int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
     const int64_t jac = 12 * nnz + 36 * n + 4, res = 12 * nnz + 28 * n + 4;
     const int64_t restr = 4 * (nc + 1) + 12 * nnzP + 8 * nc;
     const bool fused = h->ctx->opt_fuse && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && lv.T && lv.T->aggregation &&
-                       lv.A->rows == lv.A->cols && lv.A->max_block_nnz <= lv.A->lds_cap;
+                       lv.A->rows == lv.A->cols;
     if (fused) { tot += (12 * nnz + 36 * n + 4) + restr + (12 * nnz + 40 * n + 8 * nc + 4); continue; }
     if (h->nu1 > 0) tot += 24 * n + (int64_t)(h->nu1 - 1) * jac + res;   // shortcut + sweeps + residual
     // ν1 = 0: r = b, no residual pass
@@ -492,7 +492,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   //      no separate (ωD⁻¹)b / prolong-add kernels
   const bool can_fuse = ctx->opt_fuse && zero_guess && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && L.wd &&
                         L.wd_omega == h->omega && L.T->aggregation && L.A->rows == L.A->cols &&
-                        L.A->max_block_nnz <= L.A->lds_cap && L.A->lds_cap > 0;
+                        L.A->lds_cap > 0;
   if (can_fuse) {
     // x1 = wd∘b (into tmp), r = b − A·x1
     MGS_TRY(mgs_launch_fused(L.A, FUSE_PRE, L.wd->d, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));

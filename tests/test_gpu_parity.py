@@ -326,3 +326,45 @@ def test_cpp_dropin_driver(orc, inputs, golden, tmp_path):
         assert np.linalg.norm(Ao.residual(x, b)) / np.linalg.norm(b) < 1.5e-6
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Incorrect number of arguments." in r.stdout       # bicg.cpp:140-144
+
+
+def test_edge_cases(ctx, mg, orc):
+    """degenerate inputs: 1x1 operator, matrix without entries, single-level hierarchy, empty aggregate,
+    aliasing and shape errors reported loudly"""
+    A1 = ctx.csr(1, 1, [0, 1], [0], [4.0])
+    h1 = mg.Hierarchy(A1, 0.5, 1, 1).finalize()           # one level: the dense solve only
+    assert h1.nlev == 1 and h1.vcycle(ctx.vec([2.0])).numpy().tolist() == [0.5]
+    Z = ctx.csr(5, 5, [0, 0, 0, 0, 0, 0], [], [])
+    assert Z.spmv(ctx.vec(np.ones(5))).numpy().tolist() == [0.0] * 5
+    assert Z.residual(ctx.vec(np.ones(5)), ctx.vec(np.arange(5.0))).numpy().tolist() == [0, 1, 2, 3, 4]
+    with pytest.raises(mg.MgsError) as e:
+        Z.diag_inv()
+    assert e.value.code == -5
+    Ao = orc.poisson2d(8); A = dev(ctx, Ao); n = 64
+    x = ctx.vec(n)
+    with pytest.raises(mg.MgsError):                       # out of place only
+        A.jacobi(A.diag_inv(), 0.5, x, x, x)
+    with pytest.raises(mg.MgsError):
+        A.spmv(ctx.vec(3))                                 # x too short
+    with pytest.raises(mg.MgsError):                       # unsorted columns rejected at upload
+        ctx.csr(2, 2, [0, 2, 2], [1, 0], [1.0, 1.0])
+    # P with an empty aggregate (column without entries): coarse row is empty → loud numeric error
+    import scipy.sparse as sps
+    agg = np.arange(n) // 4; agg[agg >= 5] += 1            # aggregate 5 never used
+    Po = orc.Csr.from_scipy(sps.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, agg.max() + 1)))
+    with pytest.raises(mg.MgsError) as e:
+        mg.Hierarchy(A, 0.5, 1, 1).push_P(dev(ctx, Po))
+    assert e.value.code == -5
+    # V-cycle before finalize
+    h = mg.Hierarchy(A, 0.5, 1, 1)
+    with pytest.raises(mg.MgsError) as e:
+        h.vcycle(ctx.vec(n))
+    assert e.value.code == -6
+    # V(0,1), V(2,2), V(1,0) against the oracle on a G0-free two-level hierarchy
+    P2 = orc.Csr.from_scipy(sps.csr_matrix((np.ones(n), (np.arange(n), np.arange(n) // 4)), shape=(n, 16)))
+    h = mg.Hierarchy(A, 0.7, 1, 1).push_P(dev(ctx, P2)).finalize()
+    ho = orc.Hier(Ao, [P2], omega=0.7, nu1=1, nu2=1)
+    b_np = orc.rand_rhs(n); b = ctx.vec(b_np)
+    for (n1, n2) in [(0, 1), (2, 2), (1, 0), (0, 0), (3, 1)]:
+        h.set_smoother(0.7, n1, n2); ho.set_smoother(0.7, n1, n2)
+        assert rel(h.vcycle(b).numpy(), ho.vcycle(b_np)) <= 1e-12, (n1, n2)
