@@ -368,3 +368,48 @@ def test_edge_cases(ctx, mg, orc):
     for (n1, n2) in [(0, 1), (2, 2), (1, 0), (0, 0), (3, 1)]:
         h.set_smoother(0.7, n1, n2); ho.set_smoother(0.7, n1, n2)
         assert rel(h.vcycle(b).numpy(), ho.vcycle(b_np)) <= 1e-12, (n1, n2)
+
+
+def test_properties_full_size_512(ctx, mg):
+    """BASELINE.json configs[4] at full size (512^3, 1.34e8 rows, 9.4e8 entries): size-independent
+    properties of the kernels and of the whole device-built cycle."""
+    N = 512; n = N ** 3
+    A = ctx.poisson3d(N)
+    assert A.nnz == 7 * n - 6 * N * N == 937951232
+    # A·1 = number of missing neighbours (exact in FP64)
+    y = A.spmv(ctx.vec(n).fill(1.0)).numpy().reshape(N, N, N)
+    idx = np.arange(N); edge = ((idx == 0) | (idx == N - 1)).astype(np.float64)
+    assert np.array_equal(y, edge[:, None, None] + edge[None, :, None] + edge[None, None, :])
+    del y
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 1024, 32).finalize()
+    rows = [h.level_shape(l)[0] for l in range(h.nlev)]
+    assert h.nlev >= 8 and all(rows[i] > 2.5 * rows[i + 1] for i in range(len(rows) - 2)) and rows[-1] <= 1024
+    # level 1 of the 7-point operator coarsened by aligned pairs of pairs is again a 7-point operator
+    r1, nnz1 = h.level_shape(1)
+    assert abs(r1 - n / 4) < 0.001 * n and nnz1 / r1 < 7.1
+    u = ctx.vec(n).rand(seed=11); v = ctx.vec(n).rand(seed=12)
+    Bu = h.vcycle(u); Bv = h.vcycle(v)
+    # the cycle is a linear operator: B(2u − 3v) = 2Bu − 3Bv
+    w = ctx.vec(n); mg.lib().mgs_axpbypcz(2.0, u.h, -3.0, v.h, 0.0, w.h)
+    Bw = h.vcycle(w)
+    t = ctx.vec(n); mg.lib().mgs_axpbypcz(2.0, Bu.h, -3.0, Bv.h, 0.0, t.h)
+    mg.lib().mgs_axpby(-1.0, Bw.h, 1.0, t.h)
+    assert t.nrm2() <= 1e-12 * Bw.nrm2()
+    # symmetric operator + symmetric smoothing (ν1 = ν2, same ω) ⇒ symmetric preconditioner: <Bu,v> = <u,Bv>
+    a, b_ = Bu.dot(v), u.dot(Bv)
+    assert abs(a - b_) <= 1e-10 * abs(a), (a, b_)
+    # ... and positive: <Bu,u> > 0
+    assert Bu.dot(u) > 0
+    # fused passes vs one kernel per step at full size
+    ctx.set_option("fuse", 0)
+    try:
+        Bu0 = h.vcycle(u)
+    finally:
+        ctx.set_option("fuse", 1)
+    mg.lib().mgs_axpby(-1.0, Bu.h, 1.0, Bu0.h)
+    assert Bu0.nrm2() <= 1e-12 * Bu.nrm2()
+    # 30 preconditioned BiCGSTAB iterations: the recurrence residual it reports is the true residual
+    x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, u, h, 30, 1e-12)
+    assert st == 1 and it == 30 and tol < 0.2, (st, it, tol)          # status 1 = max_iter (bicg.cpp:134-135)
+    true = A.residual(x, u).nrm2() / u.nrm2()
+    assert abs(true - tol) <= 1e-6 * tol, (true, tol)
