@@ -170,6 +170,11 @@ int mgs_hier_coarsen(mgs_hier *h, double ktg, int npass, double tou, int coarse_
 /* factor the coarsest operator; must be called once before mgs_vcycle.                */
 int mgs_hier_finalize(mgs_hier *h);
 int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
+/* K-cycle (docs/AGMG_For_Convection_Diffusion.pdf §3.1, Fortran `nlvcyc`
+ * src/CPU_Matlab/dagtwolev_mex.f90:59-61,72): the coarse problems of levels 1..levels are solved
+ * by two GCR steps preconditioned by the cycle below instead of one recursive cycle.  0 = V-cycle
+ * (default).  Scalars stay on the device; ignored on row-sharded hierarchies.               */
+int mgs_hier_set_kcycle(mgs_hier *h, int levels);
 int mgs_hier_destroy(mgs_hier *h);
 int mgs_hier_nlev(const mgs_hier *h);
 int mgs_hier_level_shape(const mgs_hier *h, int level, int *rows, int64_t *nnz);
@@ -192,6 +197,14 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess);
  * to *status; the function's own return value is the MGS_* error class.               */
 int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h,
                  int *max_iter, double *tol, int *status);
+
+/* Flexible GCR(m) — the outer Krylov method AGMG pairs with the K-cycle, whose preconditioner is
+ * not a fixed linear operator (BiCGSTAB may break down with it).  Restarted every `restart`
+ * directions; same in/out convention as mgs_bicgstab (status 0 converged / 1 max_iter).  Not in the
+ * reference's C++ (its Matlab driver calls pcg/bicgstab, src/CPU_Matlab/solve.m:28-33); provided
+ * with the K-cycle.                                                      */
+int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int restart,
+             int *max_iter, double *tol, int *status);
 
 /* ------------------------------------------------------------- multi-GPU row shards   */
 /* Halo plan of a row-range shard whose CSR uses LOCAL column numbering: columns

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "mgs_hier_coarsen": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]),
     "mgs_hier_finalize": (C.c_int, [C.c_void_p]),
     "mgs_hier_set_smoother": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
+    "mgs_hier_set_kcycle": (C.c_int, [C.c_void_p, C.c_int]),
     "mgs_hier_destroy": (C.c_int, [C.c_void_p]),
     "mgs_hier_nlev": (C.c_int, [C.c_void_p]),
     "mgs_hier_level_shape": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_i64_p]),
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "mgs_hier_vcycle_bytes": (C.c_int64, [C.c_void_p]),
     "mgs_vcycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mgs_bicgstab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_dbl_p, c_int_p]),
+    "mgs_fgcr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_int_p, c_dbl_p, c_int_p]),
     "mgs_halo_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgs_hier_set_halo_exchange": (C.c_int, [C.c_void_p, HALO_FN, C.c_void_p]),
     "mgs_aggregate_shard": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),

@@ -286,6 +286,9 @@ class Hierarchy:
     def set_smoother(self, omega, nu1, nu2):
         check(lib().mgs_hier_set_smoother(self.h, omega, nu1, nu2), self.ctx.h); return self
 
+    def set_kcycle(self, levels):
+        check(lib().mgs_hier_set_kcycle(self.h, levels), self.ctx.h); return self
+
     @property
     def nlev(self):
         return lib().mgs_hier_nlev(self.h)
@@ -342,4 +345,11 @@ def bicgstab(A, x, b, hier=None, max_iter=10000, tol=1e-6):
     """BiCGSTABiml (reference bicg.cpp:74-136) → (status, iterations, achieved_tol)"""
     mi, t, st = C.c_int(max_iter), C.c_double(tol), C.c_int(-1)
     check(lib().mgs_bicgstab(A.h, x.h, b.h, hier.h if hier else None, C.byref(mi), C.byref(t), C.byref(st)), A.ctx.h)
+    return st.value, mi.value, t.value
+
+
+def fgcr(A, x, b, hier=None, restart=10, max_iter=1000, tol=1e-6):
+    """flexible GCR(restart) for the K-cycle preconditioner → (status, iterations, achieved_tol)"""
+    mi, t, st = C.c_int(max_iter), C.c_double(tol), C.c_int(-1)
+    check(lib().mgs_fgcr(A.h, x.h, b.h, hier.h if hier else None, restart, C.byref(mi), C.byref(t), C.byref(st)), A.ctx.h)
     return st.value, mi.value, t.value

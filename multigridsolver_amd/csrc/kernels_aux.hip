@@ -118,6 +118,28 @@ __global__ __launch_bounds__(TB) void dot_final_kernel(int nb, const double *__r
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// ------------------------------------------------------------------ K-cycle helpers (device-resident scalars)
+// Two GCR steps on the coarse problem (Notay, SISC 34 (2012), K-cycle for nonsymmetric problems): scal =
+// {ρ1 = v1·v1, α1 = v1·r, γ = v2·v1, β = v2·v2, α2 = v2·r'}; no host round trip, graph-capturable.
+__global__ void kc_update_r_kernel(int n, const double *__restrict__ scal, const double *__restrict__ r, const double *__restrict__ v1, double *__restrict__ rp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double rho1 = scal[0], a = rho1 != 0.0 ? scal[1] / rho1 : 0.0;
+  rp[i] = r[i] - a * v1[i];
+}
+__global__ void kc_combine_kernel(int n, const double *__restrict__ scal, const double *__restrict__ c1, const double *__restrict__ c2, double *__restrict__ x) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double rho1 = scal[0], alpha1 = scal[1], gamma = scal[2], beta = scal[3], alpha2 = scal[4];
+  double k1 = 0.0, k2 = 0.0;
+  if (rho1 != 0.0) {
+    const double rho2 = beta - gamma * gamma / rho1;
+    k1 = alpha1 / rho1;
+    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= gamma * k2 / rho1; }
+  }
+  x[i] = k1 * c1[i] + k2 * c2[i];
+}
+
 // ------------------------------------------------------------------ coarsest level: dense
 // x = A⁻¹ b with the explicit inverse (stands in for SparseLU::solve, reference bicg.cpp:48).
 // One wavefront per row, lanes stride the columns (coalesced), shuffle reduction.
@@ -344,6 +366,26 @@ int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out
     int rc = ctx->allreduce(ctx->allreduce_user, out_host, 1);
     if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
   }
+  return MGS_OK;
+}
+
+int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev) {
+  int nb = (int)((n + TB - 1) / TB);
+  if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, out_dev);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp) {
+  if (n) hipLaunchKernelGGL(kc_update_r_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, scal, r, v1, rp);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_kc_combine(mgs_ctx *ctx, int n, const double *scal, const double *c1, const double *c2, double *x) {
+  if (n) hipLaunchKernelGGL(kc_combine_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, scal, c1, c2, x);
+  MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
 

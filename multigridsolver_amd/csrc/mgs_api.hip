@@ -286,6 +286,8 @@ static void level_free(mgs_level &L) {
   if (L.own_A && L.A) mgs_csr_destroy(const_cast<mgs_csr *>(L.A));
   if (L.T) mgs_xfer_destroy(L.T);
   mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x); mgs_vec_destroy(L.wd);
+  mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
+  if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
 }
 static void drop_graph(mgs_hier *h) {
@@ -319,6 +321,11 @@ int mgs_hier_destroy(mgs_hier *h) {
 int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2) {
   MGS_CHECK(h->ctx, nu1 >= 0 && nu2 >= 0, MGS_ERR_INVALID, "negative sweep count");
   h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; drop_graph(h);
+  return MGS_OK;
+}
+int mgs_hier_set_kcycle(mgs_hier *h, int levels) {
+  MGS_CHECK(h->ctx, levels >= 0, MGS_ERR_INVALID, "mgs_hier_set_kcycle: negative level count");
+  h->kcycle_levels = levels; drop_graph(h);
   return MGS_OK;
 }
 int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user) { h->halo = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
@@ -479,6 +486,35 @@ static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, c
   return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
 }
 
+static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero_guess);
+
+// Approximate solve of the level-l problem A_l x = rhs from x = 0 for the level above.  V-cycle: one
+// recursive cycle.  K-cycle (levels 1..kcycle_levels): two GCR steps preconditioned by that cycle
+// (docs/AGMG_For_Convection_Diffusion.pdf §3.1; Fortran `nlvcyc`, src/CPU_Matlab/dagtwolev_mex.f90:59-61):
+//   c1 = B rhs, v1 = A c1, r' = rhs − (α1/ρ1) v1;  c2 = B r', v2 = A c2;
+//   x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1.
+static bool kcycle_here(const mgs_hier *h, int l) {
+  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && !h->halo && !h->halo_begin && h->lev[l].kscal;
+}
+static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
+  if (!kcycle_here(h, l)) return cycle_level(h, l, rhs, x, true);
+  mgs_ctx *ctx = h->ctx;
+  mgs_level &L = h->lev[l];
+  const int n = L.n;
+  double *sc = L.kscal;
+  MGS_TRY(cycle_level(h, l, rhs, L.kc1->d, true));
+  MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_SPMV, L.kc1->d, nullptr, nullptr, 0.0, L.kv1->d));
+  MGS_TRY(k_dot_dev(ctx, n, L.kv1->d, L.kv1->d, sc + 0));
+  MGS_TRY(k_dot_dev(ctx, n, L.kv1->d, rhs, sc + 1));
+  MGS_TRY(k_kc_update_r(ctx, n, sc, rhs, L.kv1->d, L.kr->d));
+  MGS_TRY(cycle_level(h, l, L.kr->d, L.kc2->d, true));
+  MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_SPMV, L.kc2->d, nullptr, nullptr, 0.0, L.kv2->d));
+  MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kv1->d, sc + 2));
+  MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kv2->d, sc + 3));
+  MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kr->d, sc + 4));
+  return k_kc_combine(ctx, n, sc, L.kc1->d, L.kc2->d, x);
+}
+
 static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero_guess) {
   mgs_ctx *ctx = h->ctx;
   mgs_level &L = h->lev[l];
@@ -497,7 +533,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     // x1 = wd∘b (into tmp), r = b − A·x1
     MGS_TRY(mgs_launch_fused(L.A, FUSE_PRE, L.wd->d, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));
     MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
-    MGS_TRY(cycle_level(h, l + 1, C.b->d, C.x->d, true));
+    MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
     return mgs_launch_fused(L.A, FUSE_POST, L.wd->d, L.r->d, L.tmp->d, L.T->agg, C.x->d, x, nullptr);
   }
@@ -519,7 +555,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   // restriction
   if (L.T->aggregation) MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, r, C.b->d));
   else MGS_TRY(mgs_launch_csr_op(L.T->Pt, MGS_OP_SPMV, r, nullptr, nullptr, 0.0, C.b->d));
-  MGS_TRY(cycle_level(h, l + 1, C.b->d, C.x->d, true));
+  MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
   // prolongation / correction
   if (L.T->aggregation) MGS_TRY(k_prolong_agg(ctx, n, L.T->agg, C.x->d, cur, zero ? 0 : 1));
   else if (zero) MGS_TRY(mgs_launch_csr_op(L.T->P, MGS_OP_SPMV, C.x->d, nullptr, nullptr, 0.0, cur));
@@ -538,6 +574,13 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 // wd = ω·dinv of every level that can run the fused passes; allocated and filled outside any stream capture
 static int prepare_fused(mgs_hier *h) {
   mgs_ctx *ctx = h->ctx;
+  for (int l = 1; l <= h->kcycle_levels && l < (int)h->lev.size() - 1; ++l) {
+    mgs_level &L = h->lev[l];
+    if (L.kscal) continue;
+    for (mgs_vec **q : {&L.kc1, &L.kv1, &L.kc2, &L.kv2, &L.kr}) MGS_TRY(mgs_vec_create(ctx, L.n_ext, q));
+    MGS_TRY(mgs_dev_alloc(ctx, &L.kscal, 8));
+    drop_graph(h);
+  }
   if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || h->halo || h->halo_begin) return MGS_OK;
   for (size_t l = 0; l + 1 < h->lev.size(); ++l) {
     mgs_level &L = h->lev[l];
@@ -649,6 +692,55 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     if (omega == 0) { *tol = resid; *status = 3; return mgs_sync(ctx); }              // :128-131
   }
   *tol = resid; *status = 1;                                                          // :134-135
+  return mgs_sync(ctx);
+}
+
+// Flexible GCR(m): x += Σ α_k c_k with c_k = B_k r (variable preconditioner), v_k = A c_k orthogonalised
+// (modified Gram-Schmidt) against the window's previous v_j.
+int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int restart, int *max_iter, double *tol, int *status) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, max_iter && tol && status && restart >= 1 && restart <= 64, MGS_ERR_INVALID, "mgs_fgcr: bad arguments");
+  MGS_CHECK(ctx, A->rows == A->cols && x->n >= A->rows && b->n >= A->rows, MGS_ERR_INVALID, "mgs_fgcr: square unsharded operator required");
+  const int n = A->rows;
+  struct Guard { std::vector<mgs_vec *> vs; ~Guard() { for (auto q : vs) mgs_vec_destroy(q); } } guard;
+  auto mk = [&](mgs_vec **q) -> int { int rc = mgs_vec_create(ctx, n, q); if (rc == MGS_OK) guard.vs.push_back(*q); return rc; };
+  mgs_vec *r = nullptr; MGS_TRY(mk(&r));
+  std::vector<mgs_vec *> C((size_t)restart, nullptr), V((size_t)restart, nullptr);
+  std::vector<double> rho((size_t)restart, 0.0);
+  mgs_vec xv; xv.ctx = ctx; xv.n = n; xv.d = x->d; xv.owns = false;
+  mgs_vec bv; bv.ctx = ctx; bv.n = n; bv.d = b->d; bv.owns = false;
+  double normb = 0, nr = 0, t = 0;
+  MGS_TRY(mgs_nrm2(&bv, &normb));
+  if (normb == 0.0) normb = 1;
+  MGS_TRY(mgs_residual(A, &xv, &bv, r));
+  MGS_TRY(mgs_nrm2(r, &nr));
+  double resid = nr / normb;
+  if (resid <= *tol) { *tol = resid; *max_iter = 0; *status = 0; return MGS_OK; }
+  int it = 0;
+  while (it < *max_iter) {
+    for (int k = 0; k < restart && it < *max_iter; ++k) {
+      if (!C[k]) { MGS_TRY(mk(&C[k])); MGS_TRY(mk(&V[k])); }
+      if (h) MGS_TRY(mgs_vcycle(h, r, C[k], 1)); else MGS_TRY(mgs_vec_copy(r, C[k]));
+      MGS_TRY(mgs_spmv(A, C[k], V[k]));
+      for (int j = 0; j < k; ++j) {
+        MGS_TRY(mgs_dot(V[j], V[k], &t));
+        const double beta = rho[j] != 0.0 ? t / rho[j] : 0.0;
+        MGS_TRY(mgs_axpby(-beta, V[j], 1.0, V[k]));
+        MGS_TRY(mgs_axpby(-beta, C[j], 1.0, C[k]));
+      }
+      MGS_TRY(mgs_dot(V[k], V[k], &rho[k]));
+      ++it;
+      if (rho[k] == 0.0) { *tol = resid; *max_iter = it; *status = 2; return mgs_sync(ctx); }
+      MGS_TRY(mgs_dot(V[k], r, &t));
+      const double alpha = t / rho[k];
+      MGS_TRY(mgs_axpby(alpha, C[k], 1.0, &xv));
+      MGS_TRY(mgs_axpby(-alpha, V[k], 1.0, r));
+      MGS_TRY(mgs_nrm2(r, &nr));
+      resid = nr / normb;
+      if (resid < *tol) { *tol = resid; *max_iter = it; *status = 0; return mgs_sync(ctx); }
+    }
+  }
+  *tol = resid; *max_iter = it; *status = 1;
   return mgs_sync(ctx);
 }
 

@@ -79,6 +79,8 @@ struct mgs_level {
   int n_ext = 0;          // owned + halo
   mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
   mgs_vec *wd = nullptr;       // ω·dinv (fused passes)
+  mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
+  double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
   mgs_vec *b = nullptr, *x = nullptr;  // coarse-level rhs / solution (levels >= 1)
 };
@@ -89,6 +91,7 @@ struct mgs_hier {
   double omega = 0.5;
   int nu1 = 1, nu2 = 1;
   bool finalized = false;
+  int kcycle_levels = 0;   // levels 1..kcycle_levels solve their coarse problem with 2 GCR steps (K-cycle)
   // coarsest direct solve
   int nc = 0;
   double *inv = nullptr;  // nc*nc dense inverse (row-major)
@@ -148,6 +151,9 @@ int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double
 int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z);
 int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host);
 int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *x);
+int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev);
+int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp);
+int k_kc_combine(mgs_ctx *ctx, int n, const double *scal, const double *c1, const double *c2, double *x);
 int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out);
 int k_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out);
 int k_poisson2d(mgs_ctx *ctx, int n, mgs_csr **out);

@@ -307,6 +307,8 @@ struct orc_hier {
   double **dinv, **r, **tmp, **bc, **xc;
   orc_dense_lu lu;
   double omega; int nu1, nu2;
+  int kcycle_levels;
+  double **kc1, **kv1, **kc2, **kv2, **kr;
 };
 
 orc_hier *orc_hier_create(int nlev, const orc_csr *const *A, const orc_csr *const *P,
@@ -321,11 +323,16 @@ orc_hier *orc_hier_create(int nlev, const orc_csr *const *A, const orc_csr *cons
   h->tmp = (double **)calloc((size_t)nlev, sizeof(double *));
   h->bc = (double **)calloc((size_t)nlev, sizeof(double *));
   h->xc = (double **)calloc((size_t)nlev, sizeof(double *));
+  h->kc1 = (double **)calloc((size_t)nlev, sizeof(double *)); h->kv1 = (double **)calloc((size_t)nlev, sizeof(double *));
+  h->kc2 = (double **)calloc((size_t)nlev, sizeof(double *)); h->kv2 = (double **)calloc((size_t)nlev, sizeof(double *));
+  h->kr = (double **)calloc((size_t)nlev, sizeof(double *));
   for (int l = 0; l < nlev; l++) {
     csr_copy(A[l], &h->A[l]);
     int n = A[l]->rows; size_t sz = sizeof(double) * (size_t)(n > 0 ? n : 1);
     h->dinv[l] = (double *)malloc(sz); h->r[l] = (double *)malloc(sz); h->tmp[l] = (double *)malloc(sz);
     h->bc[l] = (double *)malloc(sz); h->xc[l] = (double *)malloc(sz);
+    h->kc1[l] = (double *)malloc(sz); h->kv1[l] = (double *)malloc(sz); h->kc2[l] = (double *)malloc(sz);
+    h->kv2[l] = (double *)malloc(sz); h->kr[l] = (double *)malloc(sz);
     orc_diag_inv(&h->A[l], h->dinv[l]);
     if (l < nlev - 1) { csr_copy(P[l], &h->P[l]); orc_transpose(&h->P[l], &h->Pt[l]); }
   }
@@ -351,7 +358,9 @@ void orc_hier_destroy(orc_hier *h) {
   for (int l = 0; l < h->nlev; l++) {
     orc_csr_free(&h->A[l]); orc_csr_free(&h->P[l]); orc_csr_free(&h->Pt[l]);
     free(h->dinv[l]); free(h->r[l]); free(h->tmp[l]); free(h->bc[l]); free(h->xc[l]);
+    free(h->kc1[l]); free(h->kv1[l]); free(h->kc2[l]); free(h->kv2[l]); free(h->kr[l]);
   }
+  free(h->kc1); free(h->kv1); free(h->kc2); free(h->kv2); free(h->kr);
   if (h->lu.lu) orc_dense_lu_free(&h->lu);
   free(h->A); free(h->P); free(h->Pt); free(h->dinv); free(h->r); free(h->tmp); free(h->bc); free(h->xc);
   free(h);
@@ -359,6 +368,7 @@ void orc_hier_destroy(orc_hier *h) {
 
 int orc_hier_nlev(const orc_hier *h) { return h->nlev; }
 void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2) { h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; }
+void orc_hier_set_kcycle(orc_hier *h, int levels) { h->kcycle_levels = levels; }
 const orc_csr *orc_hier_A(const orc_hier *h, int l) { return &h->A[l]; }
 
 /* V-cycle definition (SURVEY §7 "Hard parts"; two-level ν1=0, ν2=1 from x=0
@@ -366,6 +376,33 @@ const orc_csr *orc_hier_A(const orc_hier *h, int l) { return &h->A[l]; }
  *   ν1 × { x ← x + ωD⁻¹(b − Ax) };  r = b − Ax;  r_c = Pᵀ r   (bicg.cpp:48)
  *   e_c = cycle(l+1, r_c) from 0 (coarsest: direct solve, bicg.cpp:35-36,48)
  *   x ← x + P e_c (bicg.cpp:48);  ν2 × { x ← x + ωD⁻¹(b − Ax) }            */
+static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int zero_guess);
+
+/* Coarse solve for the level above: one cycle (V), or two GCR steps preconditioned by the cycle
+ * (K-cycle; docs/AGMG_For_Convection_Diffusion.pdf §3.1 — derived from the paper, the reference's
+ * C++ has no K-cycle):  x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1. */
+static void coarse_solve_rec(const orc_hier *h, int l, const double *rhs, double *x) {
+  if (!(l >= 1 && l <= h->kcycle_levels && l < h->nlev - 1)) { vcycle_rec(h, l, rhs, x, 1); return; }
+  const orc_csr *A = &h->A[l];
+  int n = A->rows;
+  double *c1 = h->kc1[l], *v1 = h->kv1[l], *c2 = h->kc2[l], *v2 = h->kv2[l], *rp = h->kr[l];
+  vcycle_rec(h, l, rhs, c1, 1);
+  orc_spmv(A, c1, v1);
+  double rho1 = orc_dot(n, v1, v1), alpha1 = orc_dot(n, v1, rhs);
+  double a = rho1 != 0.0 ? alpha1 / rho1 : 0.0;
+  for (int i = 0; i < n; i++) rp[i] = rhs[i] - a * v1[i];
+  vcycle_rec(h, l, rp, c2, 1);
+  orc_spmv(A, c2, v2);
+  double gamma = orc_dot(n, v2, v1), beta = orc_dot(n, v2, v2), alpha2 = orc_dot(n, v2, rp);
+  double k1 = 0.0, k2 = 0.0;
+  if (rho1 != 0.0) {
+    double rho2 = beta - gamma * gamma / rho1;
+    k1 = alpha1 / rho1;
+    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= gamma * k2 / rho1; }
+  }
+  for (int i = 0; i < n; i++) x[i] = k1 * c1[i] + k2 * c2[i];
+}
+
 static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int zero_guess) {
   const orc_csr *A = &h->A[l];
   int n = A->rows;
@@ -378,7 +415,7 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
   }
   orc_residual(A, x, b, r);
   orc_spmv(&h->Pt[l], r, h->bc[l + 1]);
-  vcycle_rec(h, l + 1, h->bc[l + 1], h->xc[l + 1], 1);
+  coarse_solve_rec(h, l + 1, h->bc[l + 1], h->xc[l + 1]);
   orc_spmv(&h->P[l], h->xc[l + 1], tmp);
   for (int i = 0; i < n; i++) x[i] += tmp[i];
   for (int s = 0; s < h->nu2; s++) {

@@ -413,3 +413,35 @@ def test_properties_full_size_512(ctx, mg):
     assert st == 1 and it == 30 and tol < 0.2, (st, it, tol)          # status 1 = max_iter (bicg.cpp:134-135)
     true = A.residual(x, u).nrm2() / u.nrm2()
     assert abs(true - tol) <= 1e-6 * tol, (true, tol)
+
+
+def test_kcycle_vs_oracle(ctx, mg, orc):
+    """K-cycle: device-resident GCR scalars; GPU vs the oracle's restatement of the same
+    algorithm on the downloaded hierarchy, and fewer Krylov iterations than the V-cycle."""
+    import scipy.sparse as sps
+    N = 20
+    A = ctx.poisson3d(N); n = N ** 3
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=60, max_levels=10).finalize()
+    assert h.nlev >= 4
+    Ao = orc.poisson3d(N); Ps = []
+    for l in range(h.nlev - 1):
+        T = h.level_P(l); agg = T.agg(); nf, nc = T.shape
+        rows = np.nonzero(agg >= 0)[0]
+        Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(rows.size), (rows, agg[rows])), shape=(nf, nc))))
+    ho = orc.Hier(Ao, Ps, omega=0.6, nu1=1, nu2=1)
+    b_np = orc.rand_rhs(n); b = ctx.vec(b_np)
+    for kl in (1, 2, 3):
+        h.set_kcycle(kl); ho.set_kcycle(kl)
+        assert rel(h.vcycle(b).numpy(), ho.vcycle(b_np)) <= 1e-9, kl
+    x = ctx.vec(n); st, it_k, tol = mg.bicgstab(A, x, b, h, 300, 1e-10)
+    h.set_kcycle(0)
+    x0 = ctx.vec(n); st0, it_v, tol0 = mg.bicgstab(A, x0, b, h, 300, 1e-10)
+    assert st == 0 and st0 == 0 and it_k < it_v, (it_k, it_v)
+    assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10
+    # flexible GCR is the outer method meant for the (nonlinear) K-cycle preconditioner
+    h.set_kcycle(3)
+    xg = ctx.vec(n); stg, itg, tolg = mg.fgcr(A, xg, b, h, 10, 300, 1e-10)
+    assert stg == 0 and itg <= 2 * it_k + 5
+    assert np.linalg.norm(Ao.residual(xg.numpy(), b_np)) / np.linalg.norm(b_np) <= 3e-10
+    xi = ctx.vec(n); sti, iti, toli = mg.fgcr(A, xi, b, None, 10, 5000, 1e-8)    # unpreconditioned GCR(10)
+    assert sti == 0 and iti > itg
