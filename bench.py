@@ -200,7 +200,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(0 if os.environ.get("MGS_DIST_SHARE_GPU") else local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("MGS_FORCE_SHARDED"):   # MGS_FORCE_SHARDED: rehearse the sharded code path on one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29755")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from multigridsolver_amd import dist as mgdist
         return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes)
 
