@@ -467,10 +467,11 @@ __global__ void plan_count_kernel(int n, const int *__restrict__ rowptr, int nbl
 }
 
 __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
-                            int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
+                            unsigned long long *__restrict__ farsum /* Σ_rows max |col−row| (owned columns) */, int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
                                                     [3]=#row blocks touching halo columns,[4]=min block without halo,[5]=max block without halo*/) {
   int vb = blockIdx.x * blockDim.x + threadIdx.x;
   int mx = 0, mr = 0, far = 0;
+  unsigned long long fsum = 0;
   if (vb < nblocks) {
     bool halo = false;
     int r0 = vb * RB, r1 = min(r0 + RB, n);
@@ -480,15 +481,17 @@ __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__
       const int a = rowptr[r], e = rowptr[r + 1];
       mr = max(mr, e - a);
       if (e > a) {   // sorted row: extremes are the first entry and the last owned entry
-        far = max(far, r - col[a]);
+        int rf = max(0, r - col[a]);
         int k = e - 1;
         if (col[k] >= n) halo = true;
         while (k > a && col[k] >= n) --k;
-        if (col[k] < n) far = max(far, col[k] - r);
+        if (col[k] < n) rf = max(rf, col[k] - r);
+        far = max(far, rf); fsum += (unsigned long long)rf;
       }
     }
     if (halo) atomicAdd(&out[3], 1);
     else { atomicMin(&out[4], vb); atomicMax(&out[5], vb); }
+    atomicAdd(farsum, fsum);
   }
   for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_down(mx, off)); mr = max(mr, __shfl_down(mr, off)); far = max(far, __shfl_down(far, off)); }
   if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], mx); atomicMax(&out[1], mr); atomicMax(&out[2], far); }
@@ -549,16 +552,21 @@ int mgs_plan_csr(mgs_csr *A) {
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
   int *d = nullptr;
-  MGS_TRY(mgs_dev_alloc(ctx, &d, 7));
-  const int init[7] = {0, 0, 0, 0, 0x7fffffff, -1, 0};
+  MGS_TRY(mgs_dev_alloc(ctx, &d, 10));   // 7 ints + one 8-byte aligned 64-bit sum at d[8..9]
+  const int init[10] = {0, 0, 0, 0, 0x7fffffff, -1, 0, 0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, A->col, nblocks, d);
-  int h[7] = {0, 0, 0, 0, 0, 0, 0};
+  hipLaunchKernelGGL(plan_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, A->col, nblocks,
+                     reinterpret_cast<unsigned long long *>(d + 8), d);
+  int h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_HIP(ctx, hipFree(d));
   A->max_row_len = h[1];
-  A->far_band = h[2];
+  // typical far-band distance = mean over rows of the row's farthest owned column (the max is set by a few
+  // odd-shaped boundary aggregates on coarse levels and would mis-size the strip-major sweep)
+  unsigned long long fs; memcpy(&fs, &h[8], sizeof fs);
+  A->far_band = A->rows ? (int)(fs / (unsigned long long)A->rows) : 0;
+  A->far_band_max = h[2];
   // row blocks that read halo columns: usable for overlap when they form a prefix + suffix of the shard
   A->halo_lo_blocks = A->halo_hi_blocks = 0; A->halo_split_ok = false;
   if (A->cols > A->rows) {

@@ -43,7 +43,8 @@ struct mgs_csr {
   bool owns = true;
   // launch plan of the row-block stream kernel (computed at upload)
   int max_row_len = 0;
-  int far_band = 0;  // max |col - row| over owned columns
+  int far_band = 0;      // typical (mean over rows) farthest owned column distance
+  int far_band_max = 0;  // max |col - row| over owned columns
   int halo_lo_blocks = 0, halo_hi_blocks = 0;  // leading / trailing row blocks that read halo columns
   bool halo_split_ok = false;                  // no other block does → interior rows can overlap the exchange
   int lds_cap = 0;  // entries staged per block
