@@ -620,7 +620,7 @@ int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double
   int per_xcd = bm.chunk;
   if (bm.remap && ctx->opt_strip != 0) {
     const int D = (A->far_band + RB - 1) / RB;
-    if (D >= 256 && bm.chunk >= 2 * D) {
+    if (D >= 512 && bm.chunk >= 2 * D) {
       bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
       per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
     }
@@ -650,7 +650,7 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
   // range holds at least two planes
   if (bm.remap && ctx->opt_strip != 0) {
     const int D = (A->far_band + RB - 1) / RB;
-    if (D >= 256 && bm.chunk >= 2 * D) {
+    if (D >= 512 && bm.chunk >= 2 * D) {
       bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
       const int strips = (D + bm.S - 1) / bm.S;
       per_xcd = strips * bm.P * bm.S;
