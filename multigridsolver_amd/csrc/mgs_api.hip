@@ -291,8 +291,7 @@ static void level_free(mgs_level &L) {
   L = mgs_level();
 }
 static void drop_graph(mgs_hier *h) {
-  if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
-  h->graph_b = nullptr; h->graph_x = nullptr; h->graph_zero = -1;
+  for (auto &g : h->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); g = mgs_hier::GraphSlot(); }
 }
 
 extern "C" {
@@ -606,25 +605,34 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
   const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
-  if (h->graph && h->graph_fuse != ctx->opt_fuse) drop_graph(h);
+  if (h->graph_fuse != ctx->opt_fuse) drop_graph(h);
   h->graph_fuse = ctx->opt_fuse;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {
-    if (!(h->graph && h->graph_b == b->d && h->graph_x == xw && h->graph_zero == (zero_guess != 0))) {
-      drop_graph(h);
+    const int zg = zero_guess != 0;
+    mgs_hier::GraphSlot *slot = nullptr, *victim = &h->graphs[0];
+    for (auto &g : h->graphs) {
+      if (g.exec && g.b == b->d && g.x == xw && g.zero == zg) { slot = &g; break; }
+      if (!g.exec) { if (victim->exec) victim = &g; }
+      else if (victim->exec && g.stamp < victim->stamp) victim = &g;
+    }
+    if (!slot) {
+      if (victim->exec) { hipGraphExecDestroy(victim->exec); *victim = mgs_hier::GraphSlot(); }
       hipGraph_t g = nullptr;
       MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      int rc = cycle_level(h, 0, b->d, xw, zero_guess != 0);
+      int rc = cycle_level(h, 0, b->d, xw, zg != 0);
       hipError_t e = hipStreamEndCapture(ctx->stream, &g);
       if (rc != MGS_OK) { if (g) hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      e = hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(&victim->exec, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
-      if (e != hipSuccess) { h->graph = nullptr; return mgs_fail(ctx, MGS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-      h->graph_b = b->d; h->graph_x = xw; h->graph_zero = zero_guess != 0;
+      if (e != hipSuccess) { victim->exec = nullptr; return mgs_fail(ctx, MGS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+      victim->b = b->d; victim->x = xw; victim->zero = zg;
+      slot = victim;
     }
-    MGS_HIP(ctx, hipGraphLaunch(h->graph, ctx->stream));
+    slot->stamp = ++h->graph_clock;
+    MGS_HIP(ctx, hipGraphLaunch(slot->exec, ctx->stream));
   }
   if (staged) MGS_HIP(ctx, hipMemcpyAsync(x->d, xw, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream));
   return MGS_OK;

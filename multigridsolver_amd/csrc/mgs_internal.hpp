@@ -102,10 +102,11 @@ struct mgs_hier {
   mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
   void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle
-  hipGraphExec_t graph = nullptr;
-  const double *graph_b = nullptr;
-  double *graph_x = nullptr;
-  int graph_zero = -1;
+  // small cache of captured cycles keyed by (b, x, zero_guess): BiCGSTAB alternates two (rhs, out) pairs
+  struct GraphSlot { hipGraphExec_t exec = nullptr; const double *b = nullptr; double *x = nullptr; int zero = -1; unsigned long long stamp = 0; };
+  static constexpr int kGraphSlots = 4;
+  GraphSlot graphs[kGraphSlots];
+  unsigned long long graph_clock = 0;
   int graph_fuse = -1;
 };
 
