@@ -225,6 +225,16 @@ int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user);
  * of the rows of a plane-sharded stencil operator.  Falls back to fn for levels whose halo
  * readers are not a prefix + suffix of the row range.                                          */
 int mgs_hier_set_halo_exchange_split(mgs_hier *h, mgs_halo_fn begin, mgs_halo_fn end, void *user);
+/* Payload exchange of the fused cycle passes on a row shard.  kind 0: the peers need x1 = wd∘b of the
+ * rows they see as halo (a = wd, b = the right-hand side); kind 1: they need (P e_c) = e_c[agg] of those
+ * rows (a = e_c, b = agg as const int*).  phase 0 packs (mgs_halo_pack_prod / mgs_halo_pack_pe) and
+ * starts the exchange into halo_out (n_halo doubles), phase 1 waits for it.  Without this callback a
+ * sharded hierarchy runs the one-kernel-per-step form.                                            */
+typedef int (*mgs_halo_fused_fn)(void *user, int level, int kind, const void *a, const void *b, void *halo_out, int phase);
+int mgs_hier_set_halo_exchange_fused(mgs_hier *h, mgs_halo_fused_fn fn, void *user);
+int mgs_halo_pack_prod(mgs_ctx *ctx, const void *wd_dev, const void *b_dev, const int *send_idx_dev, int64_t n_send, double *send_buf_dev);
+int mgs_halo_pack_pe(mgs_ctx *ctx, const void *ec_dev, const void *agg_dev, const int *send_idx_dev, int64_t n_send, double *send_buf_dev);
+
 /* Building blocks of a row-sharded hierarchy (one process per GPU; orchestration in
  * multigridsolver_amd/dist.py).  mgs_aggregate_shard: pairwise aggregation of the OWNED
  * rows only (aggregates never straddle a shard; couplings to halo columns enter s_i and the

@@ -14,6 +14,7 @@ c_dbl_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 COARSE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+HALO_FUSED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_dbl_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol declared in include/mgs.h
@@ -84,6 +85,9 @@ PROTOTYPES = {
     "mgs_hier_push_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_xfer_from_agg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(C.c_void_p)]),
     "mgs_hier_set_coarse_solver": (C.c_int, [C.c_void_p, COARSE_FN, C.c_void_p]),
+    "mgs_hier_set_halo_exchange_fused": (C.c_int, [C.c_void_p, HALO_FUSED_FN, C.c_void_p]),
+    "mgs_halo_pack_prod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mgs_halo_pack_pe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgs_hier_set_halo_exchange_split": (C.c_int, [C.c_void_p, HALO_FN, HALO_FN, C.c_void_p]),
     "mgs_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mgs_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),

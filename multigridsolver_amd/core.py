@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import ALLREDUCE_FN, HALO_FN, MgsError, check, lib
+from ._lib import ALLREDUCE_FN, HALO_FN, HALO_FUSED_FN, MgsError, check, lib
 
 OP_SPMV, OP_RESIDUAL, OP_JACOBI = 0, 1, 2
 
@@ -329,6 +329,16 @@ class Hierarchy:
             return HALO_FN(_cb)
         self._cb2 = (mk(begin), mk(end))
         check(lib().mgs_hier_set_halo_exchange_split(self.h, self._cb2[0], self._cb2[1], None), self.ctx.h)
+
+    def set_halo_exchange_fused(self, fn):
+        """fn(level, kind, a_ptr, b_ptr, halo_out_ptr, phase) — payload exchange of the fused passes"""
+        def _cb(_u, level, kind, a, b, out, phase):
+            try:
+                fn(level, kind, a, b, out, phase); return 0
+            except Exception:  # noqa: BLE001
+                import traceback; traceback.print_exc(); return 1
+        self._cb3 = HALO_FUSED_FN(_cb)
+        check(lib().mgs_hier_set_halo_exchange_fused(self.h, self._cb3, None), self.ctx.h)
 
     def set_halo_exchange(self, fn):
         """fn(level:int, x_dev_ptr:int) -> None"""

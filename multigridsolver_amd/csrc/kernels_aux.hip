@@ -93,6 +93,16 @@ __global__ void gather_kernel(const double *__restrict__ x, const int *__restric
   if (i < n) out[i] = x[idx[i]];
 }
 
+// halo payloads of the fused passes on row shards: the peer needs x1 = wd∘b resp. (Pe) = e_c[agg] of my rows
+__global__ void gather_prod_kernel(const double *__restrict__ wd, const double *__restrict__ b, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int r = idx[i]; out[i] = wd[r] * b[r]; }
+}
+__global__ void gather_pe_kernel(const double *__restrict__ ec, const int *__restrict__ agg, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int a = agg[idx[i]]; out[i] = a >= 0 ? ec[a] : 0.0; }
+}
+
 // ------------------------------------------------------------------ reductions
 // Two-stage deterministic dot: fixed grid of partials (independent of scheduling), then one
 // block folds them in index order.  reference bicg.cpp:64-72 (dot/norm helpers).
@@ -353,6 +363,16 @@ int k_gather(mgs_ctx *ctx, const double *x, const int *idx, int64_t n, double *o
   return MGS_OK;
 }
 
+int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out) {
+  if (n) hipLaunchKernelGGL(gather_prod_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, wd, b, idx, n, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out) {
+  if (n) hipLaunchKernelGGL(gather_pe_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, ec, agg, idx, n, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
 int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host) {
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;

@@ -249,20 +249,23 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 template <int OP, bool STAGED>
 __device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc, const int *__restrict__ csrc, int a, int e,
                                                 const double *__restrict__ wd, const double *__restrict__ bvec,
-                                                const int *__restrict__ agg, const double *__restrict__ ec) {
+                                                const int *__restrict__ agg, const double *__restrict__ ec,
+                                                int n_owned, const double *__restrict__ hv /*values of the halo columns (row shards)*/) {
   double s = 0.0;
   for (int k = a; k < e; k += 8) {
     double xv[8];
     const int rem = e - k;
     if (OP == FUSE_PRE) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { if (q < rem) { const int c = csrc[k + q]; xv[q] = wd[c] * bvec[c]; } else xv[q] = 0.0; }
+      for (int q = 0; q < 8; ++q) {
+        if (q < rem) { const int c = csrc[k + q]; xv[q] = c < n_owned ? wd[c] * bvec[c] : hv[c - n_owned]; } else xv[q] = 0.0;
+      }
     } else {
-      int av[8];
+      int av[8], cv[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) av[q] = q < rem ? agg[csrc[k + q]] : -1;
+      for (int q = 0; q < 8; ++q) { cv[q] = q < rem ? csrc[k + q] : -1; av[q] = (cv[q] >= 0 && cv[q] < n_owned) ? agg[cv[q]] : -1; }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
+      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : (cv[q] >= n_owned ? hv[cv[q] - n_owned] : 0.0);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q < rem) s += vsrc[k + q] * xv[q];
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ wd, const double *__restrict__ bvec /*PRE: b, POST: r*/, const double *__restrict__ xin /*POST: x*/,
     const int *__restrict__ agg, const double *__restrict__ ec, double *__restrict__ out /*PRE: r, POST: x''*/,
-    double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm) {
+    double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm, const double *__restrict__ hv) {
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     __syncthreads();
   }
   if (row < r1) {
-    const double s = staged ? fused_row_sum<OP, true>(vals, cols, ga - start, ge - start, wd, bvec, agg, ec)
-                            : fused_row_sum<OP, false>(val, col, ga, ge, wd, bvec, agg, ec);
+    const double s = staged ? fused_row_sum<OP, true>(vals, cols, ga - start, ge - start, wd, bvec, agg, ec, n, hv)
+                            : fused_row_sum<OP, false>(val, col, ga, ge, wd, bvec, agg, ec, n, hv);
     if (OP == FUSE_PRE) { out[row] = bi - s; out2[row] = wi * bi; }
     else out[row] = (xi + pei) + wi * (bi - s);
   }
@@ -609,11 +612,16 @@ int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b
 // fused passes (see csr_rowblock_fused_kernel); returns MGS_ERR_STATE when the level cannot use them
 int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
                      const double *ec, double *out, double *out2) {
+  return mgs_launch_fused_range(A, which, wd, bvec, xin, agg, ec, out, out2, nullptr, 0, (A->rows + RB - 1) / RB);
+}
+// row blocks [blk_lo, blk_hi); hv = values of the halo columns (nullptr for a square operator)
+int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
+                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi) {
   mgs_ctx *ctx = A->ctx;
-  if (A->rows == 0) return MGS_OK;
-  if (A->rows != A->cols || A->lds_cap <= 0) return MGS_ERR_STATE;
+  if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
+  if (A->lds_cap <= 0 || (A->rows != A->cols && !hv)) return MGS_ERR_STATE;
   BlockMap bm;
-  bm.base = 0; bm.nblocks = (A->rows + RB - 1) / RB;
+  bm.base = blk_lo; bm.nblocks = blk_hi - blk_lo;
   bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
   bm.chunk = (bm.nblocks + 7) / 8;
   bm.D = 0; bm.S = 0; bm.P = 0;
@@ -628,8 +636,8 @@ int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
-  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm);
-  else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm);
+  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv);
+  else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

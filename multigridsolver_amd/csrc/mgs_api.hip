@@ -286,6 +286,7 @@ static void level_free(mgs_level &L) {
   if (L.own_A && L.A) mgs_csr_destroy(const_cast<mgs_csr *>(L.A));
   if (L.T) mgs_xfer_destroy(L.T);
   mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x); mgs_vec_destroy(L.wd);
+  mgs_vec_destroy(L.hbuf);
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
@@ -322,6 +323,9 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2) {
   h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; drop_graph(h);
   return MGS_OK;
 }
+int mgs_hier_set_halo_exchange_fused(mgs_hier *h, mgs_halo_fused_fn fn, void *user) { h->halo_fused = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
+int mgs_halo_pack_prod(mgs_ctx *ctx, const void *wd, const void *b, const int *idx, int64_t n, double *buf) { return k_gather_prod(ctx, (const double *)wd, (const double *)b, idx, n, buf); }
+int mgs_halo_pack_pe(mgs_ctx *ctx, const void *ec, const void *agg, const int *idx, int64_t n, double *buf) { return k_gather_pe(ctx, (const double *)ec, (const int *)agg, idx, n, buf); }
 int mgs_hier_set_kcycle(mgs_hier *h, int levels) {
   MGS_CHECK(h->ctx, levels >= 0, MGS_ERR_INVALID, "mgs_hier_set_kcycle: negative level count");
   h->kcycle_levels = levels; drop_graph(h);
@@ -525,16 +529,34 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   mgs_level &C = h->lev[l + 1];
   // ---- fused form (square unsharded level, aggregation P, V(1,1) from x = 0): two matrix passes,
   //      no separate (ωD⁻¹)b / prolong-add kernels
-  const bool can_fuse = ctx->opt_fuse && zero_guess && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && L.wd &&
-                        L.wd_omega == h->omega && L.T->aggregation && L.A->rows == L.A->cols &&
-                        L.A->lds_cap > 0;
+  const bool sharded = h->halo || h->halo_begin;
+  const bool can_fuse = ctx->opt_fuse && zero_guess && h->nu1 == 1 && h->nu2 == 1 && L.wd && L.wd_omega == h->omega &&
+                        L.T->aggregation && L.A->lds_cap > 0 &&
+                        (sharded ? (h->halo_fused != nullptr && (L.A->rows == L.A->cols || L.hbuf)) : L.A->rows == L.A->cols);
   if (can_fuse) {
+    const bool halo = L.A->cols > L.A->rows;
+    const double *hv = halo ? L.hbuf->d : nullptr;
+    const int nb = (L.A->rows + 255) / 256;
+    // interior row blocks run while the payload of the halo columns is in flight
+    const int lo = (halo && L.A->halo_split_ok) ? L.A->halo_lo_blocks : 0, hi = (halo && L.A->halo_split_ok) ? nb - L.A->halo_hi_blocks : nb;
+    auto fused_pass = [&](int which, int kind, const void *pa, const void *pb, const double *bvec, const double *xin, const int *agg,
+                          const double *ec, double *out, double *out2) -> int {
+      if (!halo) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, nullptr, 0, nb);
+      int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
+      if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
+      if (L.A->halo_split_ok) MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, lo, hi));
+      rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 1);
+      if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (end) failed at level %d (%d)", l, rc);
+      if (!L.A->halo_split_ok) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, nb);
+      MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo));
+      return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, hi, nb);
+    };
     // x1 = wd∘b (into tmp), r = b − A·x1
-    MGS_TRY(mgs_launch_fused(L.A, FUSE_PRE, L.wd->d, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));
+    MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));
     MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
-    return mgs_launch_fused(L.A, FUSE_POST, L.wd->d, L.r->d, L.tmp->d, L.T->agg, C.x->d, x, nullptr);
+    return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, L.tmp->d, L.T->agg, C.x->d, x, nullptr);
   }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
   int swaps = h->nu2 + (zero_guess ? (h->nu1 > 0 ? h->nu1 - 1 : 0) : h->nu1);
@@ -580,11 +602,14 @@ static int prepare_fused(mgs_hier *h) {
     MGS_TRY(mgs_dev_alloc(ctx, &L.kscal, 8));
     drop_graph(h);
   }
-  if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || h->halo || h->halo_begin) return MGS_OK;
+  const bool sharded = h->halo || h->halo_begin;
+  if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || (sharded && !h->halo_fused)) return MGS_OK;
   for (size_t l = 0; l + 1 < h->lev.size(); ++l) {
     mgs_level &L = h->lev[l];
-    if (!L.T || !L.T->aggregation || L.A->rows != L.A->cols) continue;
+    if (!L.T || !L.T->aggregation) continue;
+    if (L.A->rows != L.A->cols && !h->halo_fused) continue;
     if (!L.wd) MGS_TRY(mgs_vec_create(ctx, L.n, &L.wd));
+    if (L.A->cols > L.A->rows && !L.hbuf) MGS_TRY(mgs_vec_create(ctx, L.A->cols - L.A->rows, &L.hbuf));
     if (L.wd_omega != h->omega) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
   }
   return MGS_OK;

@@ -80,6 +80,7 @@ struct mgs_level {
   int n_ext = 0;          // owned + halo
   mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
   mgs_vec *wd = nullptr;       // ω·dinv (fused passes)
+  mgs_vec *hbuf = nullptr;     // halo payload of the fused passes (row shards)
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -99,6 +100,7 @@ struct mgs_hier {
   mgs_halo_fn halo = nullptr;
   void *halo_user = nullptr;
   mgs_halo_fn halo_begin = nullptr, halo_end = nullptr;   // split-phase exchange (overlap with interior rows)
+  mgs_halo_fused_fn halo_fused = nullptr;                  // payload exchange of the fused passes on row shards
   mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
   void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle
@@ -142,6 +144,10 @@ int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b
                       const double *dinv, double omega, double *out);
 int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b,
                             const double *dinv, double omega, double *out, int blk_lo, int blk_hi);
+int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
+                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi);
+int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
+int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);

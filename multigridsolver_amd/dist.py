@@ -252,8 +252,28 @@ class ShardedHierarchy:
         if w is not None:
             w.wait()
 
+    def _exchange_fused(self, level, kind, a_ptr, b_ptr, out_ptr, phase):
+        """payload of the fused passes: kind 0 → wd[idx]*b[idx], kind 1 → e_c[agg[idx]]; lands in out_ptr"""
+        if phase == 1:
+            w = self._pending.pop(("f", level), None)
+            if w is not None:
+                w.wait()
+            return
+        plan = self.plans[level]
+        ns, nr = sum(plan.send_counts), plan.n_halo
+        if ns == 0 and nr == 0:
+            return
+        buf = self._bufs[level]
+        if ns:
+            fn = lib().mgs_halo_pack_prod if kind == 0 else lib().mgs_halo_pack_pe
+            check(fn(self.ctx.h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_void_p(plan.dev_send_idx.data_ptr()), ns, C.c_void_p(buf.data_ptr())), self.ctx.h)
+        recv = self._view(out_ptr, max(nr, 1))[:nr]
+        big = plan.n_loc >= self.overlap_min_rows
+        self.n_exchanges += 1
+        self._pending[("f", level)] = self.comm.a2a_f64(recv, buf[:ns], plan.recv_counts, plan.send_counts, async_op=big)
+
     # ---- setup
-    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=1024, max_levels=32, log=None, overlap=True):
+    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=1024, max_levels=32, log=None, overlap=True, fused=True):
         comm, ctx = self.comm, self.ctx
         self._prepare_plan(0)
         A = self.A
@@ -286,6 +306,8 @@ class ShardedHierarchy:
             self.h.set_halo_exchange_split(self._exchange_begin, self._exchange_end)
         else:
             self.h.set_halo_exchange(self._exchange)
+        if fused:
+            self.h.set_halo_exchange_fused(self._exchange_fused)
         return self
 
     def _build_tail(self, ktg, npass, tou, coarse_rows, log):

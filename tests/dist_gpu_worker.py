@@ -23,6 +23,7 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     tail_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
     overlap = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
+    fused = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -34,7 +35,7 @@ def main():
     n_loc, n_ext = A.shape
     sh = mgd.ShardedHierarchy(ctx, A, mgd.poisson_plane_plan(N, world, rank), 0.6, 1, 1, comm)
     sh.overlap_min_rows = 0   # exercise the asynchronous form on every level
-    sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap)
+    sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap, fused=fused)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     n2 = N * N
     bg = orc.rand_rhs(N ** 3)

@@ -13,11 +13,12 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,N,tail,overlap", [(2, 20, 1500, 1), (3, 18, 800, 1), (2, 40, 3000, 1), (2, 20, 1500, 0)])
-def test_sharded_vcycle_matches_oracle(world, N, tail, overlap):
+@pytest.mark.parametrize("world,N,tail,overlap,fused", [(2, 20, 1500, 1, 1), (3, 18, 800, 1, 1), (2, 40, 3000, 1, 1), (2, 20, 1500, 0, 1),
+                                                        (2, 20, 1500, 1, 0), (3, 18, 800, 0, 0)])
+def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     port = 29600 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), str(overlap)]
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), str(overlap), str(fused)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
