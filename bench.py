@@ -177,7 +177,25 @@ def cpu_baseline(mg, args):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit_json(obj):
+    """the ONE JSON line, written to the process's original stdout"""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is not None:
+        os.write(_REAL_STDOUT, line)
+    else:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+
+
 def main():
+    # Libraries print banners on fd 1 (RCCL: "RCCL version : ...", Gloo: "[Gloo] Rank ..."); keep stdout
+    # clean for the one JSON line by pointing fd 1 at stderr for everything else.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -209,7 +227,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29755")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from multigridsolver_amd import dist as mgdist
-        return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes)
+        return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json)
 
     ctx = mg.Context(local_rank)
     N = args.grid
@@ -306,7 +324,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             log("cpu_baseline failed:", repr(e))
             out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    emit_json(out)
 
 
 if __name__ == "__main__":

@@ -384,7 +384,7 @@ class ShardedHierarchy:
 
 
 # ------------------------------------------------------------------ bench leg for N > 1
-def bench_sharded(args, rank, world, local_rank, log, spmv_bytes):
+def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None):
     """strong scaling: the args.grid^3 problem split by plane ranges over `world` GPUs"""
     import json
     import time
@@ -456,7 +456,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes):
                             "ms_per_launch": ms_k, "ms_spmv_with_halo_exchange": ms_x},
                "solve_check": {"bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol},
                "cpu_baseline": None}
-        print(json.dumps(out), flush=True)
+        (emit_json or (lambda o: print(json.dumps(o), flush=True)))(out)
     dist.barrier()
     del sh, b, x, xs, y, A
     ctx.close()
