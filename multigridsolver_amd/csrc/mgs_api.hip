@@ -687,17 +687,18 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     if (!h) { mgs_vec ov; view(out, ov); return mgs_vec_copy(in, &ov); }
     return mgs_vcycle(h, in, out, 1);
   };
-  double rho_1 = 0, rho_2 = 0, alpha = 0, beta = 0, omega = 0, resid = 0, normb = 0, tmp = 0, tmp2 = 0;
+  double rho_1 = 0, rho_2 = 0, alpha = 0, beta = 0, omega = 0, resid = 0, normb = 0, tmp = 0;
   MGS_TRY(mgs_nrm2(&bv, &normb));                                                     // :80
   if (halo0(const_cast<mgs_vec *>(xin))) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
   MGS_TRY(mgs_residual(A, xin, &bv, r));                                              // :82
   MGS_TRY(mgs_vec_copy(r, rt));                                                       // :83
   if (normb == 0.0) normb = 1;                                                        // :85-86
-  MGS_TRY(mgs_nrm2(r, &tmp));
-  if ((resid = tmp / normb) <= *tol) { *tol = resid; *max_iter = 0; *status = 0; return MGS_OK; }   // :88-92
+  double d2[2];
+  MGS_TRY(k_dot2(ctx, n, r->d, r->d, rt->d, r->d, d2));             // ‖r‖² and (r̃,r) in one pass / one round trip
+  if ((resid = std::sqrt(d2[0]) / normb) <= *tol) { *tol = resid; *max_iter = 0; *status = 0; return MGS_OK; }   // :88-92
   for (int i = 1; i <= *max_iter; ++i) {                                              // :94
-    MGS_TRY(mgs_dot(rt, r, &rho_1));                                                  // :95
-    if (rho_1 == 0) { MGS_TRY(mgs_nrm2(r, &tmp)); *tol = tmp / normb; *status = 2; return MGS_OK; }   // :96-99
+    rho_1 = d2[1];                                                                    // :95 (computed with the last ‖r‖)
+    if (rho_1 == 0) { *tol = std::sqrt(d2[0]) / normb; *status = 2; return MGS_OK; }  // :96-99
     if (i == 1) MGS_TRY(mgs_vec_copy(r, p));                                          // :100-101
     else {
       beta = (rho_1 / rho_2) * (alpha / omega);                                       // :103
@@ -716,12 +717,12 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     MGS_TRY(precond(s, shat));                                                        // :116
     if (halo0(shat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
     MGS_TRY(mgs_spmv(A, shat, t));                                                    // :117
-    MGS_TRY(mgs_dot(t, s, &tmp)); MGS_TRY(mgs_dot(t, t, &tmp2)); omega = tmp / tmp2;  // :118
+    MGS_TRY(k_dot2(ctx, n, t->d, s->d, t->d, t->d, d2)); omega = d2[0] / d2[1];       // :118 (t·s, t·t)
     MGS_TRY(mgs_axpbypcz(alpha, &phv, omega, &shv, 1.0, &xv));                        // :119
     MGS_TRY(mgs_axpbypcz(1.0, s, -omega, t, 0.0, r));                                 // :120
     rho_2 = rho_1;                                                                    // :122
-    MGS_TRY(mgs_nrm2(r, &tmp));
-    if ((resid = tmp / normb) < *tol) { *tol = resid; *max_iter = i; *status = 0; return mgs_sync(ctx); }   // :123-127
+    MGS_TRY(k_dot2(ctx, n, r->d, r->d, rt->d, r->d, d2));                             // ‖r‖² (:123) and next (r̃,r) (:95)
+    if ((resid = std::sqrt(d2[0]) / normb) < *tol) { *tol = resid; *max_iter = i; *status = 0; return mgs_sync(ctx); }   // :123-127
     if (omega == 0) { *tol = resid; *status = 3; return mgs_sync(ctx); }              // :128-131
   }
   *tol = resid; *status = 1;                                                          // :134-135
