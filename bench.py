@@ -162,6 +162,19 @@ def cpu_baseline(mg, args):
         t = L.ref_eigen_spmv(n, n, nnz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, xs.ctypes.data, y.ctypes.data, 5)
         out["spmv_eigen_reference_gbps"] = spmv_bytes(n, nnz) / t / 1e9
         out["spmv_eigen_reference_ms"] = t * 1e3
+    so_omp = os.path.join(REPO, "oracle", "_ref", "libref_eigen_omp.so")
+    if os.path.exists(so_omp):
+        try:   # all host cores this job may use (the GPU box gives 16 CPUs per GPU)
+            nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+            L2 = C.CDLL(so_omp)
+            L2.ref_eigen_set_threads(nthr)
+            L2.ref_eigen_spmv.restype = C.c_double
+            L2.ref_eigen_spmv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            t = L2.ref_eigen_spmv(n, n, nnz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, xs.ctypes.data, y.ctypes.data, 5)
+            out["spmv_eigen_reference_all_cores_gbps"] = spmv_bytes(n, nnz) / t / 1e9
+            out["spmv_eigen_reference_all_cores_threads"] = int(L2.ref_eigen_threads())
+        except Exception as e:  # noqa: BLE001
+            out["spmv_eigen_reference_all_cores_error"] = repr(e)
     t0 = time.perf_counter()
     for _ in range(5):
         As[0].spmv(xs)

@@ -36,6 +36,8 @@ double ref_eigen_spmv(int rows, int cols, int nnz, const int *rowptr, const int 
   auto t1 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(t1 - t0).count() / (reps > 0 ? reps : 1);
 }
+int ref_eigen_threads() { return Eigen::nbThreads(); }
+void ref_eigen_set_threads(int n) { Eigen::setNbThreads(n); }
 int ref_eigen_version() { return EIGEN_WORLD_VERSION * 10000 + EIGEN_MAJOR_VERSION * 100 + EIGEN_MINOR_VERSION; }
 }
 #endif
