@@ -159,7 +159,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
 // wave instruction instead of ~12 when 64 consecutive entries are gathered) — 2.5× less L2→L1
 // traffic and TA work for the x gather.  Sum order is still the ascending column order of the
 // row, so the result stays bit-identical to the scalar CPU loop.
-template <int OP, bool NT, int LANES>
+template <int OP, bool NT, int LANES, int U>
 __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
@@ -195,23 +195,21 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     }
     __syncthreads();
     if (row < r1) {
+      // U entries per step, branch-free: the column reads past the row's end stay inside the staged slice
+      // (or its 2-entry pad) and are clamped to a valid x index; their products are replaced by +0.0, which
+      // leaves the running sum bit-identical.  All U gathers are in flight before the first add.
       double s = 0.0;
-      int k = my_a;
-      // rows of up to 8 entries: all gathers in flight before the first add
-      for (; k + 8 <= my_e; k += 8) {
-        double xv[8];
+      const int lim = hi - start - 1;                  // last staged index
+      for (int k = my_a; k < my_e; k += U) {
+        int cq[U]; double xv[U], vq[U];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xv[q] = x[cols[k + q]];
+        for (int q = 0; q < U; ++q) cq[q] = cols[min(k + q, lim)];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += vals[k + q] * xv[q];
-      }
-      {
-        double xv[8];
-        const int rem = my_e - k;
+        for (int q = 0; q < U; ++q) xv[q] = x[(k + q < my_e) ? cq[q] : row];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xv[q] = q < rem ? x[cols[k + q]] : 0.0;
+        for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) if (q < rem) s += vals[k + q] * xv[q];
+        for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
       }
       if (OP == MGS_OP_SPMV) out[row] = s;
       else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
@@ -521,10 +519,16 @@ template <int OP, bool NT>
 int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const double *b,
                  const double *dinv, double omega, double *out, int cap, BlockMap bm) {
   hipStream_t s = A->ctx->stream;
-  const size_t lds = (size_t)(cap > 0 ? cap + 2 : 2) * 12 + 16;
-#define L_(LN)                                                                                             \
-  hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN>), grid, dim3(RB), lds, s, A->rows, A->rowptr, \
-                     A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0)
+  const size_t lds = (size_t)(cap > 0 ? cap + 2 : 2) * 12 + 16 + (size_t)A->ctx->opt_lds_pad;   // opt_lds_pad: occupancy experiments
+  // U = gathers per step of the row walk: the typical row length (7-point stencils: exactly one step)
+  const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
+  const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
+#define L_(LN)                                                                                                 \
+  do {                                                                                                         \
+    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
+    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
+    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
+  } while (0)
   switch (lanes) {
     case 4: L_(4); break;
     case 8: L_(8); break;

@@ -62,6 +62,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "graph") ctx->opt_graph = value;
   else if (k == "strip") ctx->opt_strip = value;
   else if (k == "fuse") ctx->opt_fuse = value;
+  else if (k == "lds_pad") ctx->opt_lds_pad = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
 }

@@ -28,6 +28,7 @@ struct mgs_ctx {
   int opt_fuse = 1;         // fused V-cycle passes on square levels
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   mgs_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;

@@ -17,7 +17,7 @@ A = ctx.poisson3d(N)
 nnz = A.nnz
 x = ctx.vec(n).rand(seed=1); y = ctx.vec(n); b = ctx.vec(n).rand(seed=2); dinv = A.diag_inv()
 byts = 12 * nnz + 20 * n + 4
-variants = [(5, 0, 0), (5, 64, 0), (5, 128, 0), (7, 0, 0), (7, 64, 0), (7, 128, 0), (7, 32, 0)]
+variants = [(5, 64, 0), (5, 0, 0), (3, 64, 0)]
 ref = None
 times = {k: [] for k in variants}
 for rnd in range(4):
