@@ -72,3 +72,36 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(mg.MgsError) as e:
         mg.Context(0)
     assert e.value.code == -2
+
+
+def test_loader_property_random_files(orc, tmp_path):
+    """property test of the .mtx contract (MatrixIO.cpp:12-37): any entry order, any whitespace, leading
+    comment lines, scientific notation — library loader == oracle loader == scipy's own assembly"""
+    import multigridsolver_amd as mg
+    import scipy.sparse as sps
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 12), st.integers(1, 12), st.data())
+    def run(M, N, data):
+        cells = data.draw(st.lists(st.tuples(st.integers(0, M - 1), st.integers(0, N - 1)), unique=True, max_size=40))
+        vals = data.draw(st.lists(st.floats(-1e6, 1e6, allow_nan=False, width=64), min_size=len(cells), max_size=len(cells)))
+        ncom = data.draw(st.integers(0, 3))
+        seps = data.draw(st.lists(st.sampled_from([" ", "  ", "\t", " \t "]), min_size=2, max_size=2))
+        p = tmp_path / "r.mtx"
+        with open(p, "w") as f:
+            for c in range(ncom):
+                f.write("%" * (1 + c % 2) + " comment line %d\n" % c)
+            f.write(f"  {M}{seps[0]}{N}{seps[1]}{len(cells)}   \n")
+            for (i, j), v in zip(cells, vals):
+                f.write(f"{i + 1}{seps[0]}{j + 1}{seps[1]}{v!r}\n")
+        rows, cols, rp, ci, v = mg.read_mtx(str(p))
+        o = orc.Csr.read(str(p))
+        assert (rows, cols) == (M, N) == o.shape
+        assert np.array_equal(rp, o.rowptr) and np.array_equal(ci, o.col) and np.array_equal(v, o.val)
+        ref = sps.csr_matrix((vals, ([c[0] for c in cells], [c[1] for c in cells])), shape=(M, N)) if cells else sps.csr_matrix((M, N))
+        ref.sort_indices()
+        # scipy drops nothing here (explicit zeros are kept by the constructor only if present in data)
+        assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(v, ref.data)
+
+    run()
