@@ -15,7 +15,7 @@ __global__ void diag_inv_kernel(int n, const int *__restrict__ rowptr, const int
   int lo = rowptr[i], hi = rowptr[i + 1] - 1;
   double d = 0.0;
   while (lo <= hi) {
-    int mid = (lo + hi) >> 1;
+    int mid = lo + ((hi - lo) >> 1);   // lo + hi would overflow int32 near 2^31 entries
     int c = col[mid];
     if (c == i) { d = val[mid]; break; }
     if (c < i) lo = mid + 1; else hi = mid - 1;

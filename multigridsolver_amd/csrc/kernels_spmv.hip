@@ -196,7 +196,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     __syncthreads();
     if (row < r1) {
       // U entries per step, branch-free: the column reads past the row's end stay inside the staged slice
-      // (or its 2-entry pad) and are clamped to a valid x index; their products are replaced by +0.0, which
+      // and are clamped to the last staged entry, so every gathered index is a real column; their products are replaced by +0.0, which
       // leaves the running sum bit-identical.  All U gathers are in flight before the first add.
       double s = 0.0;
       const int lim = hi - start - 1;                  // last staged index
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 #pragma unroll
         for (int q = 0; q < U; ++q) cq[q] = cols[min(k + q, lim)];
 #pragma unroll
-        for (int q = 0; q < U; ++q) xv[q] = x[(k + q < my_e) ? cq[q] : row];
+        for (int q = 0; q < U; ++q) xv[q] = x[cq[q]];   // past the row's end: some staged entry's column, always a valid x index
 #pragma unroll
         for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
 #pragma unroll

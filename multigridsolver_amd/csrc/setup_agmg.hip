@@ -176,7 +176,7 @@ __global__ void galerkin_copy_kernel(int nc, const int *__restrict__ offs, const
 __device__ __forceinline__ double csr_lookup(const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val, int i, int j) {
   int lo = rowptr[i], hi = rowptr[i + 1] - 1;   // reference getElementMatrixCSR, MatrixAccess.cu:28-47
   while (lo <= hi) {
-    int mid = (lo + hi) >> 1; int c = col[mid];
+    int mid = lo + ((hi - lo) >> 1); int c = col[mid];   // (lo + hi would overflow int32 near 2^31 entries)
     if (c == j) return val[mid];
     if (c < j) lo = mid + 1; else hi = mid - 1;
   }
@@ -190,7 +190,7 @@ __global__ void pattern_asym_kernel(int n, const int *__restrict__ rowptr, const
     int j = col[k];
     if (j == i || j >= n) continue;               // halo columns (row shards) are not owned rows
     int lo = rowptr[j], hi = rowptr[j + 1] - 1; bool found = false;
-    while (lo <= hi) { int mid = (lo + hi) >> 1; int c = col[mid]; if (c == i) { found = true; break; } if (c < i) lo = mid + 1; else hi = mid - 1; }
+    while (lo <= hi) { int mid = lo + ((hi - lo) >> 1); int c = col[mid]; if (c == i) { found = true; break; } if (c < i) lo = mid + 1; else hi = mid - 1; }
     if (!found) ++bad;
   }
   if (bad) atomicAdd(asym, bad);

@@ -192,7 +192,7 @@ int orc_galerkin(const orc_csr *A, const orc_csr *P, orc_csr *Ac) {
 static double csr_coeff(const orc_csr *A, int i, int j) { /* Eigen coeff(): 0 if absent */
   int lo = A->rowptr[i], hi = A->rowptr[i + 1] - 1;
   while (lo <= hi) {
-    int mid = (lo + hi) >> 1;
+    int mid = lo + ((hi - lo) >> 1);
     if (A->col[mid] == j) return A->val[mid];
     if (A->col[mid] < j) lo = mid + 1; else hi = mid - 1;
   }

@@ -445,3 +445,63 @@ def test_kcycle_vs_oracle(ctx, mg, orc):
     assert np.linalg.norm(Ao.residual(xg.numpy(), b_np)) / np.linalg.norm(b_np) <= 3e-10
     xi = ctx.vec(n); sti, iti, toli = mg.fgcr(A, xi, b, None, 10, 5000, 1e-8)    # unpreconditioned GCR(10)
     assert sti == 0 and iti > itg
+
+
+def test_random_matrices_vs_oracle(ctx, mg, orc):
+    """seeded random sparse operators (rectangular, empty rows, skewed row lengths): every SpMV-shaped
+    kernel against the oracle; bit-exact when no row exceeds the sequential-path limit."""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        m = int(rng.integers(1, 3000)); n = int(rng.integers(1, 3000))
+        dens = float(rng.choice([0.0005, 0.003, 0.02, 0.1]))
+        M = sps.random(m, n, density=dens, random_state=rng, format="csr", dtype=np.float64)
+        M.data = rng.standard_normal(M.nnz)
+        if trial % 3 == 0 and m > 4:      # a few very long rows
+            M = M.tolil(); M[int(rng.integers(0, m)), :] = rng.standard_normal(n); M = M.tocsr()
+        M.sort_indices()
+        Ao = orc.Csr.from_scipy(M); A = dev(ctx, Ao)
+        x_np = rng.standard_normal(n); b_np = rng.standard_normal(m)
+        x = ctx.vec(x_np); b = ctx.vec(b_np)
+        y = A.spmv(x).numpy(); r = A.residual(x, b).numpy()
+        yo = Ao.spmv(x_np); ro = Ao.residual(x_np, b_np)
+        maxlen = int(np.diff(M.indptr).max()) if m else 0
+        if maxlen <= 64:
+            assert np.array_equal(y, yo) and np.array_equal(r, ro), (trial, m, n, dens)
+        else:
+            scale = np.abs(M).dot(np.abs(x_np)) + 1e-300
+            assert np.max(np.abs(y - yo) / scale) <= 1e-14 and np.max(np.abs(r - ro) / (scale + np.abs(b_np))) <= 1e-14, (trial, m, n)
+        if m <= n and m > 0:              # Jacobi on a "shard-shaped" operator (rows <= cols) with a safe diagonal
+            D = sps.csr_matrix((np.full(m, 3.0 + np.abs(M).sum(axis=1).A1.max()), (np.arange(m), np.arange(m))), shape=(m, n))
+            M2 = (M + D).tocsr(); M2.sort_indices()
+            A2o = orc.Csr.from_scipy(M2); A2 = dev(ctx, A2o)
+            dinv = A2.diag_inv()
+            assert np.array_equal(dinv.numpy(), A2o.diag_inv())
+            xj = A2.jacobi(dinv, 0.7, b, x).numpy()
+            xo = A2o.jacobi(A2o.diag_inv(), 0.7, b_np, x_np[:m] if n == m else np.concatenate([x_np[:m]]))[:m] if n == m else None
+            if n == m and int(np.diff(M2.indptr).max()) <= 64:
+                assert np.array_equal(xj[:m], xo)
+
+
+def test_max_size_int32_indices(ctx, mg):
+    """maximum size the int32 index contract allows: a 672^3 operator has 2 121 541 632 entries (98.8 % of
+    2^31); every byte offset must be computed in 64 bits.  A·1 and the diagonal are exact."""
+    N = 672; n = N ** 3
+    A = ctx.poisson3d(N)
+    assert A.nnz == 7 * n - 6 * N * N == 2121541632 < 2 ** 31
+    y = A.spmv(ctx.vec(n).fill(1.0)).numpy().reshape(N, N, N)
+    idx = np.arange(N); edge = ((idx == 0) | (idx == N - 1)).astype(np.float64)
+    assert np.array_equal(y, edge[:, None, None] + edge[None, :, None] + edge[None, None, :])
+    del y
+    d = A.diag_inv().numpy()
+    assert np.all(d == 1.0 / 6.0)
+    # the last row block (largest offsets) against a hand computation
+    x = ctx.vec(n).rand(seed=5)
+    yv = A.spmv(x)
+    xt = x.numpy()[-2 * N * N - 8:]; yt = yv.numpy()[-4:]
+    for q in range(4):
+        e = len(xt) - 4 + q; k = (n - 4 + q) % N
+        want = -xt[e - N * N] - xt[e - N] - xt[e - 1] + 6.0 * xt[e]
+        if k < N - 1:
+            want = (-xt[e - N * N] - xt[e - N] - xt[e - 1] + 6.0 * xt[e]) + (-xt[e + 1])
+        assert abs(yt[q] - want) <= 1e-14 * 10
