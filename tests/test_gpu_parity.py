@@ -505,3 +505,58 @@ def test_max_size_int32_indices(ctx, mg):
         if k < N - 1:
             want = (-xt[e - N * N] - xt[e - N] - xt[e - 1] + 6.0 * xt[e]) + (-xt[e + 1])
         assert abs(yt[q] - want) <= 1e-14 * 10
+
+
+def test_random_aggregations_and_graph_laplacians(ctx, mg, orc):
+    """randomised setup-side parity: transposes, aggregation transfers with G0 rows and aggregates of 1..16
+    members, Galerkin products and full device-built cycles on random graph Laplacians, all vs the oracle"""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(77)
+    for trial in range(8):
+        n = int(rng.integers(50, 4000))
+        # random connected-ish graph Laplacian + diagonal shift (M-matrix, nonsymmetric values on odd trials)
+        deg = int(rng.integers(2, 7))
+        rows = np.repeat(np.arange(n), deg); cols = rng.integers(0, n, size=n * deg)
+        ring = np.arange(n)
+        W = sps.csr_matrix((rng.random(n * deg) + 0.1, (rows, cols)), shape=(n, n)) + sps.csr_matrix((np.ones(n), (ring, (ring + 1) % n)), shape=(n, n))
+        W = W + W.T if trial % 2 == 0 else W + 0.5 * W.T
+        W.setdiag(0); W.eliminate_zeros()
+        A_sp = (sps.diags(np.asarray(W.sum(axis=1)).ravel() + np.asarray(W.sum(axis=0)).ravel() * 0 + 0.05) - W).tocsr(); A_sp.sort_indices()
+        Ao = orc.Csr.from_scipy(A_sp); A = dev(ctx, Ao)
+        # transpose
+        rp, ci, v = A.transpose().download(); To = Ao.transpose()
+        assert np.array_equal(rp, To.rowptr) and np.array_equal(ci, To.col) and np.array_equal(v, To.val)
+        # random aggregation: sizes 1..16, ~5 % of rows left out (G0), shuffled membership
+        sizes = []
+        while sum(sizes) < n:
+            sizes.append(int(rng.integers(1, 17)))
+        agg = np.repeat(np.arange(len(sizes)), sizes)[:n]
+        agg = agg[rng.permutation(n)]
+        agg[rng.random(n) < 0.05] = -1
+        _, inv = np.unique(agg[agg >= 0], return_inverse=True); agg[agg >= 0] = inv
+        nc = int(agg.max()) + 1
+        r = np.nonzero(agg >= 0)[0]
+        Po = orc.Csr.from_scipy(sps.csr_matrix((np.ones(r.size), (r, agg[r])), shape=(n, nc)))
+        T = mg.Xfer.from_csr(dev(ctx, Po))
+        assert T.is_aggregation and np.array_equal(T.agg(), agg)
+        vec = rng.standard_normal(n); vc = rng.standard_normal(nc)
+        assert np.array_equal(T.restrict(ctx.vec(vec)).numpy(), Po.transpose().spmv(vec))
+        assert np.array_equal(T.prolong(ctx.vec(vc)).numpy(), Po.spmv(vc))
+        xx = ctx.vec(vec); T.prolong_add(ctx.vec(vc), xx)
+        assert np.array_equal(xx.numpy(), vec + Po.spmv(vc))
+        Ac = A.galerkin(T); rp, ci, v = Ac.download(); Aco = Ao.galerkin(Po)
+        assert np.array_equal(rp, Aco.rowptr) and np.array_equal(ci, Aco.col)
+        assert np.max(np.abs(v - Aco.val)) <= 1e-13 * max(1.0, np.abs(Aco.val).max())
+        # device-built hierarchy and cycle vs the oracle cycle on the downloaded hierarchy
+        h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=40, max_levels=8).finalize()
+        Ps = []
+        for l in range(h.nlev - 1):
+            Tl = h.level_P(l); a = Tl.agg(); nf, ncl = Tl.shape; rr = np.nonzero(a >= 0)[0]
+            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(rr.size), (rr, a[rr])), shape=(nf, ncl))))
+        b_np = rng.standard_normal(n)
+        if Ps:
+            ho = orc.Hier(Ao, Ps, omega=0.6, nu1=1, nu2=1)
+            assert rel(h.vcycle(ctx.vec(b_np)).numpy(), ho.vcycle(b_np)) <= 1e-10, trial
+        x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, ctx.vec(b_np), h, 500, 1e-10)
+        assert st == 0, (trial, st, it, tol)
+        assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 2e-10
