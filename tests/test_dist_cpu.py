@@ -11,8 +11,7 @@ import pytest
 
 from conftest import REPO
 
-N = 6
-WORLD = 2
+N = 8
 
 
 def _local_poisson(orc, N, lo, hi):
@@ -92,7 +91,7 @@ def _worker(rank, world, port, q):
         assert np.allclose(yc, want, rtol=0, atol=1e-12), (np.abs(yc - want).max(), np.nonzero(np.abs(yc - want) > 1e-12)[0][:10], nc, n_halo_c, cplan.recv_counts, cplan.send_counts)
         # reductions
         a = np.array([rank + 1.0, 2.0]); comm.allreduce_host(a)
-        assert a.tolist() == [3.0, 4.0]
+        assert a.tolist() == [world * (world + 1) / 2.0, 2.0 * world]
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -116,15 +115,17 @@ def test_partition_and_plan_shapes():
                 assert len(p.send_idx[q]) == (Ng * Ng if abs(q - r) == 1 else 0)
 
 
-def test_handshake_and_exchange_world2_gloo():
+@pytest.mark.parametrize("WORLD", [2, 4])
+def test_handshake_and_exchange_gloo(WORLD):
+    """world 2 (each rank has one neighbour) and world 4 (interior ranks have two, most peer lists empty)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + WORLD
     procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(WORLD)]
+    res = [q.get(timeout=240) for _ in range(WORLD)]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:

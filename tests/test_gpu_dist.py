@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,N,tail,overlap,fused", [(2, 20, 1500, 1, 1), (3, 18, 800, 1, 1), (2, 40, 3000, 1, 1), (2, 20, 1500, 0, 1),
-                                                        (2, 20, 1500, 1, 0), (3, 18, 800, 0, 0)])
+                                                        (2, 20, 1500, 1, 0), (3, 18, 800, 0, 0), (4, 24, 1200, 1, 1)])
 def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     port = 29600 + (os.getpid() % 1000) + world
