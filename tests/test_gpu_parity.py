@@ -560,3 +560,29 @@ def test_random_aggregations_and_graph_laplacians(ctx, mg, orc):
         x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, ctx.vec(b_np), h, 500, 1e-10)
         assert st == 0, (trial, st, it, tol)
         assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 2e-10
+
+
+def test_setup_driver_and_reference_crosscheck(orc, inputs, tmp_path):
+    """mgs_agmg = the reference's setup CLI (src/CPU_C++/main.cpp:153-239, src/GPU_CUDAC++/main.cu:18-297): writes
+    <name>promatrix_gpu.mtx.  The file must equal (sha256) the one that was fed to the REAL reference's bicg in
+    the build container (tests/golden/pgpu_crosscheck.json, tools/crosscheck_pgpu.py), where it needed no more
+    iterations than the reference's own CPU-built P — the reference's end-to-end criterion (results.txt:48-51)."""
+    import hashlib, json, os, shutil, subprocess
+    from conftest import GOLD, REPO
+    exe = os.path.join(REPO, "multigridsolver_amd", "cpp", "mgs_agmg")
+    chk = json.load(open(os.path.join(GOLD, "pgpu_crosscheck.json")))["cases"]
+    root = tmp_path / "tree"; (root / "matrices").mkdir(parents=True); (root / "src" / "common").mkdir(parents=True)
+    for m in ["CSky3d30", "CSky3d10", "CSky2d20", "poisson10000"]:
+        shutil.copy(inputs[m], root / "matrices" / (m + ".mtx"))
+        r = subprocess.run([exe, m, "10", "2", "8"], cwd=root / "src" / "common", capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "P matrix successfully written." in r.stdout, r.stdout + r.stderr
+        pfile = root / "matrices" / (m + "promatrix_gpu.mtx")
+        assert hashlib.sha256(open(pfile, "rb").read()).hexdigest() == chk[m]["P_gpu_sha256"], m   # deterministic setup
+        c = chk[m]
+        assert c["ref_bicg_ilut_with_P_gpu"]["status"] == 0
+        assert c["ref_bicg_ilut_with_P_gpu"]["iterations"] <= c["ref_bicg_ilut_with_P_cpu"]["iterations"] + 1
+        # and the file is a valid aggregation P for the oracle loader: ≤ 1 unit entry per row
+        P = orc.Csr.read(str(pfile))
+        assert np.all(np.diff(P.rowptr) <= 1) and np.all(P.val == 1.0)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid arguments." in r.stdout                              # main.cpp:155-165
