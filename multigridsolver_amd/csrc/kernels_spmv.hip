@@ -240,7 +240,8 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 // Fused V-cycle passes on the slice kernel (square, unsharded levels only):
 //   FUSE_PRE : from x = 0 with ν1 = 1:  x1 = wd∘b,  r = b − A·x1   (gathers wd[c]·b[c]; one pass instead
 //              of the (ωD⁻¹)b kernel + the residual kernel; bit-identical to the two-kernel form)
-//   FUSE_POST: coarse-grid correction + one Jacobi sweep:  x'' = x + Pe + wd∘(r − A·Pe), Pe_j = ec[agg_j]
+//   FUSE_POST: coarse-grid correction + one Jacobi sweep:  x'' = x1 + Pe + wd∘(r − A·Pe), Pe_j = ec[agg_j], x1 = wd∘b
+//              recomputed from b (so the PRE pass need not store it)
 //              (r = b − Ax is the residual already computed before restriction, so b − A(x+Pe) = r − A·Pe;
 //              one pass instead of prolong-add + Jacobi; equal to the two-kernel form up to rounding)
 // wd = ω·dinv precomputed per level.
@@ -274,7 +275,7 @@ __device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc,
 template <int OP>
 __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
-    const double *__restrict__ wd, const double *__restrict__ bvec /*PRE: b, POST: r*/, const double *__restrict__ xin /*POST: x*/,
+    const double *__restrict__ wd, const double *__restrict__ bvec /*PRE: b, POST: r*/, const double *__restrict__ xin /*POST: b (x1 = wd∘b)*/,
     const int *__restrict__ agg, const double *__restrict__ ec, double *__restrict__ out /*PRE: r, POST: x''*/,
     double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm, const double *__restrict__ hv) {
   extern __shared__ double lds_raw[];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
     bi = bvec[row]; wi = wd[row];
-    if (OP == FUSE_POST) { xi = xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }
+    if (OP == FUSE_POST) { xi = wi * xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }   // x1 = wd∘b recomputed (xin = b)
   }
   if (staged) {
     const int nch = (hi - start + 1) >> 1;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   if (row < r1) {
     const double s = staged ? fused_row_sum<OP, true>(vals, cols, ga - start, ge - start, wd, bvec, agg, ec, n, hv)
                             : fused_row_sum<OP, false>(val, col, ga, ge, wd, bvec, agg, ec, n, hv);
-    if (OP == FUSE_PRE) { out[row] = bi - s; out2[row] = wi * bi; }
+    if (OP == FUSE_PRE) { out[row] = bi - s; if (out2) out2[row] = wi * bi; }
     else out[row] = (xi + pei) + wi * (bi - s);
   }
 }

@@ -430,8 +430,8 @@ int mgs_hier_finalize(mgs_hier *h) {
 int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
   // algorithmic bytes of the kernels one zero-guess cycle actually launches.
   // Every level starts from x = 0: the first pre-sweep is the 24n-byte (ωD⁻¹)b kernel, not a
-  // Jacobi pass.  Fused form (V(1,1), square level): pass A reads the matrix, wd, b and writes r, x1;
-  // pass B reads the matrix, r, x1, wd, agg, e_c and writes x.
+  // Jacobi pass.  Fused form (V(1,1)): pass A reads the matrix, wd, b and writes r;
+  // pass B reads the matrix, r, b, wd, agg, e_c and writes x.
   int64_t tot = 0;
   const int L = (int)h->lev.size();
   for (int l = 0; l < L - 1; ++l) {
@@ -441,7 +441,7 @@ int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
     const int64_t restr = 4 * (nc + 1) + 12 * nnzP + 8 * nc;
     const bool fused = h->ctx->opt_fuse && h->nu1 == 1 && h->nu2 == 1 && !h->halo && !h->halo_begin && lv.T && lv.T->aggregation &&
                        lv.A->rows == lv.A->cols;
-    if (fused) { tot += (12 * nnz + 36 * n + 4) + restr + (12 * nnz + 40 * n + 8 * nc + 4); continue; }
+    if (fused) { tot += (12 * nnz + 28 * n + 4) + restr + (12 * nnz + 40 * n + 8 * nc + 4); continue; }
     if (h->nu1 > 0) tot += 24 * n + (int64_t)(h->nu1 - 1) * jac + res;   // shortcut + sweeps + residual
     // ν1 = 0: r = b, no residual pass
     tot += restr;
@@ -552,12 +552,12 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo));
       return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, hi, nb);
     };
-    // x1 = wd∘b (into tmp), r = b − A·x1
-    MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, L.tmp->d));
+    // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
+    MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, nullptr));
     MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
-    return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, L.tmp->d, L.T->agg, C.x->d, x, nullptr);
+    return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, b, L.T->agg, C.x->d, x, nullptr);
   }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
   int swaps = h->nu2 + (zero_guess ? (h->nu1 > 0 ? h->nu1 - 1 : 0) : h->nu1);
