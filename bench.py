@@ -304,6 +304,18 @@ def main():
     st, it, tol = mg.bicgstab(A, xsol, b, h, 200, 1e-10)
     t_solve = time.perf_counter() - t0
     log(f"one cycle: |r|/|b| = {r1 / r0:.3e}; BiCGSTAB+V-cycle to 1e-10: status {st}, {it} iterations, tol {tol:.2e}, {t_solve:.2f}s")
+    # K-cycle on the first 4 coarse levels + flexible GCR(10), untimed region as well
+    h.set_kcycle(4)
+    xk = ctx.vec(n)
+    ms_kcycle = h.time_vcycle(b, xk, reps=3)
+    xk.fill(0.0); ctx.sync()
+    t0 = time.perf_counter()
+    stk, itk, tolk = mg.fgcr(A, xk, b, h, 10, 300, 1e-10)
+    t_solve_k = time.perf_counter() - t0
+    truek = A.residual(xk, b).nrm2() / r0
+    h.set_kcycle(0)
+    log(f"FGCR(10)+K-cycle(4 levels, {ms_kcycle:.2f} ms per cycle) to 1e-10: status {stk}, {itk} iterations, true residual {truek:.2e}, {t_solve_k:.2f}s")
+    del xk
 
     out = {
         "metric": "V-cycles/sec + fine-level SpMV HBM GB/s, 512³ 7-pt Poisson, 1/2/4/8 GPU",
@@ -323,7 +335,9 @@ def main():
                      "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9,
                      "vcycle_ms_unfused_form": ms_unfused},
         "solve_check": {"one_cycle_residual_reduction": r1 / r0, "bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol,
-                        "bicgstab_seconds": t_solve},
+                        "bicgstab_seconds": t_solve,
+                        "fgcr10_kcycle4": {"status": stk, "iterations": itk, "achieved_tol": tolk, "true_residual": truek,
+                                           "seconds": t_solve_k, "ms_per_kcycle": ms_kcycle}},
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
