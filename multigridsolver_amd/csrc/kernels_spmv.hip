@@ -7,7 +7,8 @@
 // Design: AMG operators of PDE problems have 3..30 entries per row, so a
 // wavefront-per-row kernel would idle ≥57 of 64 lanes.  One 256-thread workgroup owns 256
 // consecutive rows ("row block") and stages the block's contiguous slice of val/col_idx in
-// LDS with fully coalesced, non-temporal 16-/8-byte loads (every lane busy).  Then lane t walks
+// LDS with fully coalesced 16-/8-byte loads (every lane busy; plain loads — the non-temporal form
+// measured 3 % slower here and stays an option).  Then lane t walks
 // row t: the 64 lanes of a wave gather x[col] for 64 consecutive rows at once — contiguous
 // runs of x for stencil-like operators — and add the products sequentially in ascending column
 // order, the same order as Eigen's scalar loop
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_kernel(
 }
 
 // Variant B ("slice in LDS, row-parallel gather").  Phase 1 parks the block's raw val/col slice
-// in LDS (coalesced 16-byte / 8-byte non-temporal loads, no dependent gather in the streaming
+// in LDS (coalesced 16-byte / 8-byte loads, no dependent gather in the streaming
 // phase).  Phase 2: lane t walks row t; on step q the 64 lanes of a wave gather x[col] for 64
 // CONSECUTIVE rows, which for stencil-like operators is one contiguous run (4–5 cache lines per
 // wave instruction instead of ~12 when 64 consecutive entries are gathered) — 2.5× less L2→L1
