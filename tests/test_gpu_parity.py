@@ -586,3 +586,45 @@ def test_setup_driver_and_reference_crosscheck(orc, inputs, tmp_path):
         assert np.all(np.diff(P.rowptr) <= 1) and np.all(P.val == 1.0)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid arguments." in r.stdout                              # main.cpp:155-165
+
+
+def test_pattern_asymmetric_operator_setup(ctx, mg, orc):
+    """operators whose PATTERN is not symmetric (one-directional couplings, e.g. pure upwind convection): the
+    device setup takes the explicit-transpose path for s_i / G0 (reference computeRowColAbsSum merges row i of A with
+    column i, Aggregation.cu:17-64).  Checked against a direct numpy evaluation of s_i and the G0 rule, and by
+    running the built hierarchy as a preconditioner."""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(3)
+    n = 1500
+    # chain with forward-only couplings plus random one-directional long links; diagonally dominant M-matrix
+    rows = np.r_[np.arange(n - 1), rng.integers(0, n, 2 * n)]
+    cols = np.r_[np.arange(1, n), rng.integers(0, n, 2 * n)]
+    keep = rows != cols
+    W = sps.csr_matrix((rng.random(keep.sum()) + 0.2, (rows[keep], cols[keep])), shape=(n, n)); W.sum_duplicates()
+    assert (abs(W - W.T) > 0).nnz > 0 and ((W != 0) != (W.T != 0)).nnz > 0          # pattern really asymmetric
+    d = np.maximum(np.asarray(W.sum(axis=1)).ravel(), np.asarray(W.sum(axis=0)).ravel()) * 1.02 + 0.01
+    A_sp = (sps.diags(d) - W).tocsr(); A_sp.sort_indices()
+    Ao = orc.Csr.from_scipy(A_sp); A = dev(ctx, Ao)
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=0, max_levels=2)
+    agg = h.level_P(0).agg()
+    # G0 rule (AGMG.cpp:118-123): a_ii >= ktg/(ktg-2) * sum_{j != i} |a_ij + a_ji| / 2
+    S = (A_sp + A_sp.T) * 0.5; S.setdiag(0)
+    g0 = A_sp.diagonal() >= (10.0 / 8.0) * np.asarray(abs(S).sum(axis=1)).ravel()
+    assert np.array_equal(agg < 0, g0)
+    nc = h.level_shape(1)[0]
+    sizes = np.bincount(agg[agg >= 0], minlength=nc)
+    assert sizes.min() >= 1 and sizes.max() <= 4
+    # every pair that was formed satisfies the admissibility test mu <= ktg with the reference's formula (AGMG.cpp:92-99)
+    Ad = A_sp.toarray(); s = -np.asarray(S.sum(axis=1)).ravel()
+    h1 = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 1, 8.0, coarse_rows=0, max_levels=2)        # one pass: plain pairs
+    a1 = h1.level_P(0).agg()
+    for I in np.nonzero(np.bincount(a1[a1 >= 0]) == 2)[0][:200]:
+        i, j = np.nonzero(a1 == I)[0]
+        num = 2 / (1 / Ad[i, i] + 1 / Ad[j, j])
+        den = -(Ad[i, j] + Ad[j, i]) / 2 + 1 / (1 / (Ad[i, i] - s[i]) + 1 / (Ad[j, j] - s[j]))
+        assert 0 < num / den <= 10.0 * (1 + 1e-12), (i, j, num / den)
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=50, max_levels=8).finalize()
+    b_np = rng.standard_normal(n)
+    x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, ctx.vec(b_np), h, 500, 1e-10)
+    assert st == 0
+    assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 2e-10
