@@ -16,7 +16,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n = N ** 3
 nnz = 7 * n - 6 * N * N
 nc1 = None
-ALG = {"fused_pre": 12 * nnz + 36 * n + 4, "fused_post": 12 * nnz + 40 * n + 4, "spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
+ALG = {"fused_pre": 12 * nnz + 28 * n + 4, "fused_post": 12 * nnz + 40 * n + 4, "spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
        "axpby(calibration)": 32 * n}
 
 
