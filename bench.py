@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--ktg", type=float, default=10.0)
     ap.add_argument("--npass", type=int, default=2)
     ap.add_argument("--tou", type=float, default=8.0)
-    ap.add_argument("--coarse-rows", type=int, default=1024)
+    ap.add_argument("--coarse-rows", type=int, default=2500)
     ap.add_argument("--cpu-grid", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)

@@ -277,7 +277,7 @@ class Hierarchy:
     def push_P(self, P):
         check(lib().mgs_hier_push_P(self.h, P.h), self.ctx.h); return self
 
-    def coarsen(self, ktg=10.0, npass=2, tou=8.0, coarse_rows=1024, max_levels=32):
+    def coarsen(self, ktg=10.0, npass=2, tou=8.0, coarse_rows=2500, max_levels=32):
         check(lib().mgs_hier_coarsen(self.h, ktg, npass, tou, coarse_rows, max_levels), self.ctx.h); return self
 
     def finalize(self):

@@ -126,7 +126,7 @@ class DeviceMatrix {
 struct PrecondOptions {
   double omega = 0.6; int nu1 = 1, nu2 = 1;
   double ktg = 10.0; int npass = 2; double tou = 8.0;   // src/GPU_CUDAC++/results.txt:22-24
-  int coarse_rows = 1024; int max_levels = 32;
+  int coarse_rows = 2500; int max_levels = 32;   // ≤ 2500 rows: dense inverse (a GEMV beats two more latency-bound levels)
 };
 class MultiGridPrecond {
   DeviceMatrix A_;

@@ -273,7 +273,7 @@ class ShardedHierarchy:
         self._pending[("f", level)] = self.comm.a2a_f64(recv, buf[:ns], plan.recv_counts, plan.send_counts, async_op=big)
 
     # ---- setup
-    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=1024, max_levels=32, log=None, overlap=True, fused=True):
+    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=2500, max_levels=32, log=None, overlap=True, fused=True):
         comm, ctx = self.comm, self.ctx
         self._prepare_plan(0)
         A = self.A
