@@ -1,0 +1,37 @@
+"""Docs stay true: every C-ABI symbol and repo path that DESIGN.md / INTEGRATION.md / README.md mention exists."""
+import os
+import re
+
+from conftest import REPO
+
+
+def _symbols():
+    src = open(os.path.join(REPO, "include", "mgs.h")).read()
+    return set(re.findall(r"\b(mgs_[A-Za-z0-9_]+)\s*\(", src)) | set(re.findall(r"typedef struct (mgs_[a-z]+)", src)) | \
+        set(re.findall(r"\(\*(mgs_[a-z_]+)\)", src))
+
+
+def test_documented_symbols_exist():
+    syms = _symbols()
+    for doc in ["DESIGN.md", "INTEGRATION.md", "README.md"]:
+        text = open(os.path.join(REPO, doc)).read()
+        for name in set(re.findall(r"`(mgs_[A-Za-z0-9_]+)[`(]", text)):
+            if name in ("mgs_host", "mgs_bicg", "mgs_agmg", "mgs_oracle", "mgs_internal", "mgs_api", "mgs_bench_"):
+                continue
+            assert name in syms, f"{doc} mentions {name}, which include/mgs.h does not declare"
+
+
+def test_documented_paths_exist():
+    pat = re.compile(r"`((?:multigridsolver_amd|oracle|tests|tools|profiles|include)/[A-Za-z0-9_./*-]+)`")
+    for doc in ["DESIGN.md", "INTEGRATION.md", "README.md", "profiles/README.md", "tools/README.md"]:
+        text = open(os.path.join(REPO, doc)).read()
+        for path in set(pat.findall(text)):
+            path = path.rstrip(".,:")
+            if "*" in path or path.endswith("/"):
+                import glob
+                assert glob.glob(os.path.join(REPO, path.rstrip("/") + ("*" if not path.endswith("*") and not path.endswith("/") else ""))) or \
+                    os.path.isdir(os.path.join(REPO, path)), f"{doc}: no file matches {path}"
+            elif path.startswith("oracle/_ref") or path.endswith(".so") or path.endswith("mgs_bicg") or path.endswith("mgs_agmg"):
+                continue   # build outputs (git-ignored)
+            else:
+                assert os.path.exists(os.path.join(REPO, path)), f"{doc}: {path} does not exist"
