@@ -164,15 +164,17 @@ template <int OP, bool NT, int LANES, int U>
 __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
-    double *__restrict__ out, int cap, BlockMap bm, int seq_overflow) {
+    double *__restrict__ out, int cap, BlockMap bm, int seq_overflow, const int *__restrict__ blkptr) {
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
   const int r0 = (bm.base + vb) * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
-  const int lo = rowptr[r0];
-  const int hi = rowptr[r1];
+  // block bounds from the compact per-block copy of rowptr (consecutive workgroups share cache lines;
+  // rowptr[r0] itself is 1 KiB apart from block to block)
+  const int lo = blkptr ? blkptr[bm.base + vb] : rowptr[r0];
+  const int hi = blkptr ? blkptr[bm.base + vb + 1] : rowptr[r1];
   if (hi - lo <= cap) {
     double *__restrict__ vals = lds_raw;                                   // cap + 2 doubles
     int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);   // cap + 2 ints
@@ -278,15 +280,15 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ wd, const double *__restrict__ bvec /*PRE: b, POST: r*/, const double *__restrict__ xin /*POST: b (x1 = wd∘b)*/,
     const int *__restrict__ agg, const double *__restrict__ ec, double *__restrict__ out /*PRE: r, POST: x''*/,
-    double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm, const double *__restrict__ hv) {
+    double *__restrict__ out2 /*PRE: x1*/, int cap, BlockMap bm, const double *__restrict__ hv, const int *__restrict__ blkptr) {
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
   const int r0 = (bm.base + vb) * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
-  const int lo = rowptr[r0];
-  const int hi = rowptr[r1];
+  const int lo = blkptr ? blkptr[bm.base + vb] : rowptr[r0];
+  const int hi = blkptr ? blkptr[bm.base + vb + 1] : rowptr[r1];
   double *__restrict__ vals = lds_raw;
   int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
   const int row = r0 + tid;
@@ -469,6 +471,11 @@ __global__ void plan_count_kernel(int n, const int *__restrict__ rowptr, int nbl
   if (cnt > c3) atomicAdd(&out[3], 1);
 }
 
+__global__ void blkptr_kernel(int n, const int *__restrict__ rowptr, int nblocks, int *__restrict__ blkptr) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nblocks) blkptr[b] = rowptr[min(b * RB, n)];
+}
+
 __global__ void plan_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, int nblocks,
                             unsigned long long *__restrict__ farsum /* Σ_rows max |col−row| (owned columns) */, int *__restrict__ out /*[0]=max block nnz,[1]=max row len,[2]=max |col-row| over owned columns,
                                                     [3]=#row blocks touching halo columns,[4]=min block without halo,[5]=max block without halo*/) {
@@ -527,9 +534,9 @@ int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const 
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define L_(LN)                                                                                                 \
   do {                                                                                                         \
-    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
-    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
-    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0); \
+    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
+    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
+    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
   } while (0)
   switch (lanes) {
     case 4: L_(4); break;
@@ -560,6 +567,9 @@ int mgs_plan_csr(mgs_csr *A) {
   A->lds_cap = 0;
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
+  if (A->blkptr) { hipFree(A->blkptr); A->blkptr = nullptr; }
+  MGS_TRY(mgs_dev_alloc(ctx, &A->blkptr, (size_t)nblocks + 1));
+  hipLaunchKernelGGL(blkptr_kernel, dim3((nblocks + 256) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, nblocks, A->blkptr);
   int *d = nullptr;
   MGS_TRY(mgs_dev_alloc(ctx, &d, 10));   // 7 ints + one 8-byte aligned 64-bit sum at d[8..9]
   const int init[10] = {0, 0, 0, 0, 0x7fffffff, -1, 0, 0, 0, 0};
@@ -642,8 +652,8 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
-  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv);
-  else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv);
+  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
+  else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

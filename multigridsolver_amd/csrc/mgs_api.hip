@@ -63,6 +63,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "strip") ctx->opt_strip = value;
   else if (k == "fuse") ctx->opt_fuse = value;
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
+  else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
 }
@@ -133,6 +134,7 @@ int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]) {
 int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
   if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }
+  if (A->blkptr) hipFree(A->blkptr);
   delete A;
   return MGS_OK;
 }

@@ -28,6 +28,7 @@ struct mgs_ctx {
   int opt_fuse = 1;         // fused V-cycle passes on square levels
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   mgs_allreduce_fn allreduce = nullptr;
@@ -39,6 +40,7 @@ struct mgs_csr {
   int rows = 0, cols = 0;
   int64_t nnz = 0;
   int *rowptr = nullptr;  // rows+1
+  int *blkptr = nullptr;  // rowptr sampled every 256 rows (row-block bounds), built by mgs_plan_csr
   int *col = nullptr;     // nnz (+pad)
   double *val = nullptr;  // nnz (+pad)
   bool owns = true;

@@ -17,23 +17,26 @@ A = ctx.poisson3d(N)
 nnz = A.nnz
 x = ctx.vec(n).rand(seed=1); y = ctx.vec(n); b = ctx.vec(n).rand(seed=2); dinv = A.diag_inv()
 byts = 12 * nnz + 20 * n + 4
-variants = [(5, 64, 0), (5, 0, 0), (3, 64, 0)]
+variants = [(5, 64, 0), (5, 64, 0, 0)]
 ref = None
 times = {k: [] for k in variants}
-for rnd in range(4):
-    for (v, s, nt) in variants:
+for rnd in range(6):
+    for var in variants:
+        v, s, nt = var[:3]
+        ctx.set_option("blkptr", var[3] if len(var) > 3 else 1)
         ctx.set_option("spmv_variant", v); ctx.set_option("strip", s); ctx.set_option("nontemporal", nt)
         if rnd == 0:
             A.spmv(x, y); out = y.numpy()
             if ref is None:
                 ref = out
             assert np.array_equal(ref, out), (v, s, nt)
-        times[(v, s, nt)].append(A.time_kernel(mg.OP_SPMV, x, out=y, reps=10))
+        times[var].append(A.time_kernel(mg.OP_SPMV, x, out=y, reps=10))
 print(f"grid {N}^3  algorithmic bytes {byts/1e9:.3f} GB")
 print("chunk strip nt   median_ms   min_ms   GB/s(median)  frac_of_8TB/s")
-for (v, s, nt), t in sorted(times.items(), key=lambda kv: np.median(kv[1])):
+for var, t in sorted(times.items(), key=lambda kv: np.median(kv[1])):
     med, mn = float(np.median(t)), float(min(t))
-    print(f"{ {2:1,3:2,4:4,5:0,6:-1,7:-7}[v]:5d} {s:5d} {nt:2d} {med:10.3f} {mn:8.3f} {byts/med/1e6:12.0f} {byts/med/1e6/8000:10.3f}")
+    print(f"{str(var):20s} {med:10.3f} {mn:8.3f} {byts/med/1e6:12.0f} {byts/med/1e6/8000:10.3f}")
+ctx.set_option("blkptr", 1)
 # jacobi / residual with the default (auto) settings
 ctx.set_option("spmv_variant", 0); ctx.set_option("strip", -1); ctx.set_option("nontemporal", 1)
 for name, op, bb in (("spmv", mg.OP_SPMV, 12 * nnz + 20 * n), ("residual", mg.OP_RESIDUAL, 12 * nnz + 28 * n), ("jacobi", mg.OP_JACOBI, 12 * nnz + 36 * n)):
