@@ -74,6 +74,41 @@ def plane_range(N, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def row_ranges(n, world):
+    """contiguous, near-equal row ranges [lo, hi) per rank"""
+    base, rem = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi)); lo = hi
+    return out
+
+
+def shard_from_global(n, rowptr, col, val, world, rank, exchange_lists):
+    """Row shard of a global CSR operator (any sparsity): rows [lo,hi) of this rank with LOCAL column numbering —
+    owned columns first, then one halo slot per distinct off-shard column, grouped by owner rank (ascending) and
+    sorted by global column inside a group; every row re-sorted by local column.  One handshake tells each owner
+    which of its rows its peers need.  Returns (rowptr_loc, col_loc, val_loc, n_cols_loc, LevelPlan)."""
+    import scipy.sparse as sps
+    rng = row_ranges(n, world)
+    lo, hi = rng[rank]
+    n_loc = hi - lo
+    starts = np.array([r[0] for r in rng] + [n], dtype=np.int64)
+    rp = np.asarray(rowptr[lo:hi + 1], dtype=np.int64) - int(rowptr[lo])
+    ci = np.asarray(col[rowptr[lo]:rowptr[hi]], dtype=np.int64)
+    v = np.asarray(val[rowptr[lo]:rowptr[hi]], dtype=np.float64)
+    off = (ci < lo) | (ci >= hi)
+    halo_glob = np.unique(ci[off])                               # sorted ⇒ grouped by owner rank (contiguous ranges)
+    owner = np.searchsorted(starts, halo_glob, side="right") - 1
+    recv_ids = [(halo_glob[owner == p] - starts[p]).astype(np.int32) for p in range(world)]
+    loc = np.where(off, n_loc + np.searchsorted(halo_glob, ci), ci - lo)
+    m = sps.csr_matrix((v, loc, rp), shape=(n_loc, n_loc + len(halo_glob)))
+    m.sort_indices()
+    req = exchange_lists([r.astype(np.int64) for r in recv_ids])     # owners learn what to send
+    plan = LevelPlan(n_loc, [np.asarray(a, dtype=np.int32) for a in req], recv_ids)
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data, n_loc + len(halo_glob), plan
+
+
 def coarse_plan_handshake(plan, agg_loc, nc_loc, exchange_lists):
     """One setup handshake per level (host arrays only).
     agg_loc: aggregate id of every owned row (−1 = none).  exchange_lists(list_per_peer) →
