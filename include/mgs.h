@@ -167,7 +167,9 @@ int mgs_hier_push_P(mgs_hier *h, const mgs_csr *P);
  * (src/CPU_C++/main.cpp:155-182; benchmarks use 10 2 8, results.txt:22-24).           */
 int mgs_hier_coarsen(mgs_hier *h, double ktg, int npass, double tou, int coarse_rows,
                      int max_levels);
-/* factor the coarsest operator; must be called once before mgs_vcycle.                */
+/* factor the coarsest operator (dense inverse on device, ≤ 8192 rows); must be called once before
+ * mgs_vcycle.  If coarsening stalled above that size (e.g. all rows in G0) the coarsest level is
+ * smoothed by 8 damped-Jacobi sweeps instead.                                          */
 int mgs_hier_finalize(mgs_hier *h);
 int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
 /* K-cycle (docs/AGMG_For_Convection_Diffusion.pdf §3.1, Fortran `nlvcyc`

@@ -421,9 +421,17 @@ int mgs_hier_finalize(mgs_hier *h) {
   mgs_ctx *ctx = h->ctx;
   const mgs_csr *Ac = h->lev.back().A;
   MGS_CHECK(ctx, Ac->rows == Ac->cols, MGS_ERR_STATE, "coarsest operator is not square");
-  MGS_CHECK(ctx, Ac->rows <= 8192, MGS_ERR_STATE, "coarsest level has %d rows (> 8192): add levels (mgs_hier_coarsen) before finalize", Ac->rows);
   if (h->inv) { hipFree(h->inv); h->inv = nullptr; }
   h->nc = Ac->rows;
+  h->coarse_sweeps = 0;
+  if (Ac->rows > 8192) {
+    // Coarsening stopped far above the dense limit (e.g. every row is in G0: the operator is so diagonally
+    // dominant that Jacobi alone converges, AGMG.cpp:118-123).  The coarsest level is then smoothed
+    // (8 damped-Jacobi sweeps from 0) instead of solved; the cycle stays a fixed linear operator.
+    h->coarse_sweeps = 8;
+    h->finalized = true; drop_graph(h);
+    return MGS_OK;
+  }
   MGS_TRY(k_dense_inverse(ctx, Ac, &h->inv));
   h->finalized = true; drop_graph(h);
   return MGS_OK;
@@ -450,7 +458,8 @@ int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
     tot += (h->nu1 > 0 ? 20 * n : 12 * n) + 8 * nc;                        // prolong-add / prolong
     tot += (int64_t)h->nu2 * jac;
   }
-  tot += (int64_t)h->nc * h->nc * 8 + 16 * (int64_t)h->nc;
+  if (h->coarse_sweeps > 0) { const mgs_csr *Ac = h->lev.back().A; tot += 24 * (int64_t)Ac->rows + (int64_t)(h->coarse_sweeps - 1) * (12 * Ac->nnz + 36 * (int64_t)Ac->rows + 4); }
+  else tot += (int64_t)h->nc * h->nc * 8 + 16 * (int64_t)h->nc;
   return tot;
 }
 
@@ -527,6 +536,18 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   const int n = L.n;
   if (l == (int)h->lev.size() - 1) {
     if (h->coarse) { int rc = h->coarse(h->coarse_user, b, x); return rc ? mgs_fail(ctx, MGS_ERR_STATE, "coarse solver callback failed (%d)", rc) : MGS_OK; }
+    if (h->coarse_sweeps > 0) {                        // smoothed coarsest level (see mgs_hier_finalize)
+      double *cur = x, *alt = L.tmp->d;
+      if (!(h->coarse_sweeps & 1)) std::swap(cur, alt);   // odd number of buffer flips ends in x
+      MGS_TRY(k_jacobi_zero(ctx, n, h->omega, L.dinv->d, b, cur));
+      for (int s = 1; s < h->coarse_sweeps; ++s) {
+        MGS_TRY(halo_x(h, l, cur));
+        MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_JACOBI, cur, b, L.dinv->d, h->omega, alt));
+        std::swap(cur, alt);
+      }
+      if (cur != x) MGS_HIP(ctx, hipMemcpyAsync(x, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      return MGS_OK;
+    }
     return k_dense_gemv(ctx, h->nc, h->inv, b, x);
   }
   mgs_level &C = h->lev[l + 1];
@@ -627,7 +648,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   mgs_level &L0 = h->lev[0];
   MGS_CHECK(ctx, b->n >= L0.n && x->n >= L0.n, MGS_ERR_INVALID, "mgs_vcycle: vectors shorter than the operator (%d rows)", L0.n);
   MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
-  if (h->lev.size() == 1) return cycle_level(h, 0, b->d, x->d, true);
+  if (h->lev.size() == 1 && !h->coarse_sweeps) return cycle_level(h, 0, b->d, x->d, true);
   // sharded level 0 needs halo room behind the owned entries: work in the level's own buffer
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;

@@ -100,6 +100,7 @@ struct mgs_hier {
   // coarsest direct solve
   int nc = 0;
   double *inv = nullptr;  // nc*nc dense inverse (row-major)
+  int coarse_sweeps = 0;  // > 0: coarsening stalled above the dense limit → the coarsest level is smoothed, not solved
   mgs_halo_fn halo = nullptr;
   void *halo_user = nullptr;
   mgs_halo_fn halo_begin = nullptr, halo_end = nullptr;   // split-phase exchange (overlap with interior rows)

@@ -628,3 +628,24 @@ def test_pattern_asymmetric_operator_setup(ctx, mg, orc):
     x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, ctx.vec(b_np), h, 500, 1e-10)
     assert st == 0
     assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 2e-10
+
+
+def test_all_g0_operator_smoothed_coarsest(ctx, mg, orc):
+    """an operator so diagonally dominant that every row is in G0 (AGMG.cpp:118-123): nothing to aggregate, and with
+    20 000 rows the level is above the dense limit — the cycle smooths it (8 Jacobi sweeps) and stays usable"""
+    import scipy.sparse as sps
+    P = orc.poisson2d(150).to_scipy()
+    A_sp = (P + 20.0 * sps.eye(P.shape[0])).tocsr(); A_sp.sort_indices()
+    Ao = orc.Csr.from_scipy(A_sp); A = dev(ctx, Ao); n = A_sp.shape[0]
+    h = mg.Hierarchy(A, 0.8, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=1000, max_levels=10).finalize()
+    assert h.nlev == 1 and h.vcycle_bytes > 0
+    b_np = orc.rand_rhs(n); b = ctx.vec(b_np)
+    y = h.vcycle(b).numpy()
+    # 8 damped-Jacobi sweeps from zero, restated with the oracle primitives
+    dinv = Ao.diag_inv(); x = np.zeros(n)
+    for _ in range(8):
+        x = Ao.jacobi(dinv, 0.8, b_np, x)
+    assert np.array_equal(y, x)
+    xs = ctx.vec(n); st, it, tol = mg.bicgstab(A, xs, b, h, 200, 1e-10)
+    assert st == 0 and it <= 10
+    assert np.linalg.norm(Ao.residual(xs.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10
