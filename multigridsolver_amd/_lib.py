@@ -1,5 +1,8 @@
 """ctypes loader of libmgs.so (the C-ABI in include/mgs.h).
 
+Processes that also use PyTorch-ROCm (the multi-GPU launcher does, for torch.distributed) must import torch BEFORE
+this library is loaded: torch ships its own HIP runtime and the first runtime loaded serves the whole process.
+
 The library is HIP-only: if it is missing or cannot be loaded this module raises — there is
 no Python/NumPy fallback for any compute entry point.
 """
