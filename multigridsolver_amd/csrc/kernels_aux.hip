@@ -158,6 +158,29 @@ __global__ __launch_bounds__(TB) void dot2_final_kernel(int nb, const double *__
   }
 }
 
+// z = a·x + b·y fused with (z·z, w·z): BiCGSTAB's s = r − αv with ‖s‖² and r = s − ωt with (‖r‖², r̃·r) in one pass each
+__global__ __launch_bounds__(TB) void update_dot2_partial_kernel(int64_t n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
+                                                                 double *__restrict__ z, const double *__restrict__ w, double *__restrict__ part) {
+  __shared__ double sh[2][TB / 64];
+  double s0 = 0.0, s1 = 0.0;
+  int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * TB;
+  for (; i < n; i += stride) {
+    const double zi = a * x[i] + b * y[i];
+    z[i] = zi;
+    s0 += zi * zi;
+    if (w) s1 += w[i] * zi;
+  }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 // ------------------------------------------------------------------ K-cycle helpers (device-resident scalars)
 // Two GCR steps on the coarse problem (Notay, SISC 34 (2012), K-cycle for nonsymmetric problems): scal =
 // {ρ1 = v1·v1, α1 = v1·r, γ = v2·v1, β = v2·v2, α2 = v2·r'}; no host round trip, graph-capturable.
@@ -424,6 +447,21 @@ int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const doub
   if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, z, w, ctx->red_dev);
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
+  if (ctx->allreduce) {
+    int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
+    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
+  }
+  return MGS_OK;
+}
+int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2) {
+  int nb = (int)((n + TB - 1) / TB);
+  if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(update_dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
   MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -732,8 +732,8 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     if (halo0(phat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
     MGS_TRY(mgs_spmv(A, phat, v));                                                    // :107
     MGS_TRY(mgs_dot(rt, v, &tmp)); alpha = rho_1 / tmp;                               // :108
-    MGS_TRY(mgs_axpbypcz(1.0, r, -alpha, v, 0.0, s));                                 // :109
-    MGS_TRY(mgs_nrm2(s, &tmp));
+    MGS_TRY(k_update_dot2(ctx, n, 1.0, r->d, -alpha, v->d, s->d, nullptr, d2));      // :109 s = r − αv, with ‖s‖² in the same pass
+    tmp = std::sqrt(d2[0]);
     if ((resid = tmp / normb) < *tol) {                                               // :110-115
       MGS_TRY(mgs_axpby(alpha, &phv, 1.0, &xv));
       *max_iter = i; *tol = resid; *status = 0; return mgs_sync(ctx);
@@ -743,9 +743,8 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     MGS_TRY(mgs_spmv(A, shat, t));                                                    // :117
     MGS_TRY(k_dot2(ctx, n, t->d, s->d, t->d, t->d, d2)); omega = d2[0] / d2[1];       // :118 (t·s, t·t)
     MGS_TRY(mgs_axpbypcz(alpha, &phv, omega, &shv, 1.0, &xv));                        // :119
-    MGS_TRY(mgs_axpbypcz(1.0, s, -omega, t, 0.0, r));                                 // :120
+    MGS_TRY(k_update_dot2(ctx, n, 1.0, s->d, -omega, t->d, r->d, rt->d, d2));       // :120 r = s − ωt with ‖r‖² (:123) and the next (r̃,r) (:95)
     rho_2 = rho_1;                                                                    // :122
-    MGS_TRY(k_dot2(ctx, n, r->d, r->d, rt->d, r->d, d2));                             // ‖r‖² (:123) and next (r̃,r) (:95)
     if ((resid = std::sqrt(d2[0]) / normb) < *tol) { *tol = resid; *max_iter = i; *status = 0; return mgs_sync(ctx); }   // :123-127
     if (omega == 0) { *tol = resid; *status = 3; return mgs_sync(ctx); }              // :128-131
   }

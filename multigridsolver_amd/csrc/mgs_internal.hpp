@@ -164,6 +164,7 @@ int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, con
 int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host);
 int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *x);
 int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev);
+int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2);
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2);
 int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp);
 int k_kc_combine(mgs_ctx *ctx, int n, const double *scal, const double *c1, const double *c2, double *x);
