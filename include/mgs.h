@@ -272,8 +272,9 @@ int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double 
  * row-block kernel, [4]=leading and [5]=trailing row blocks that read halo columns, [6]=1 if the
  * interior/boundary split is usable, [7]=1 if some block takes the long-row path.            */
 int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
-/* kernel-variant knobs for A/B measurements (0 = default).  key: "spmv_variant",
- * "xcd_remap", "nontemporal", "graph".                                                */
+/* kernel-variant knobs for A/B measurements.  key: "spmv_variant", "xcd_remap", "nontemporal",
+ * "graph", "strip", "fuse", "fuse_operands" (setup-time operands of the fused cycle passes,
+ * +12 B of HBM per matrix entry; default 1), "lds_pad", "blkptr".  Unknown key: MGS_ERR_INVALID. */
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

@@ -93,6 +93,19 @@ __global__ void gather_kernel(const double *__restrict__ x, const int *__restric
   if (i < n) out[i] = x[idx[i]];
 }
 
+// setup-time operands of the fused cycle passes (unsharded levels): scaled values and aggregate-mapped columns
+__global__ void scale_vals_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                  const double *__restrict__ wd, double *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = val[k] * wd[col[k]];
+}
+__global__ void map_cols_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ agg, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = agg[col[k]];
+}
+
 // halo payloads of the fused passes on row shards: the peer needs x1 = wd∘b resp. (Pe) = e_c[agg] of my rows
 __global__ void gather_prod_kernel(const double *__restrict__ wd, const double *__restrict__ b, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -416,6 +429,16 @@ int k_gather(mgs_ctx *ctx, const double *x, const int *idx, int64_t n, double *o
   return MGS_OK;
 }
 
+int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out) {
+  if (A->rows) hipLaunchKernelGGL(scale_vals_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int *out) {
+  if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, agg, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out) {
   if (n) hipLaunchKernelGGL(gather_prod_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, wd, b, idx, n, out);
   MGS_HIP(ctx, hipGetLastError());

@@ -262,6 +262,12 @@ __device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc,
       for (int q = 0; q < 8; ++q) {
         if (q < rem) { const int c = csrc[k + q]; xv[q] = c < n_owned ? wd[c] * bvec[c] : hv[c - n_owned]; } else xv[q] = 0.0;
       }
+    } else if (OP == FUSE_POST_MAPPED) {
+      int av[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) av[q] = q < rem ? csrc[k + q] : -1;      // coarse column (−1: not aggregated)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
     } else {
       int av[8], cv[8];
 #pragma unroll
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
     bi = bvec[row]; wi = wd[row];
-    if (OP == FUSE_POST) { xi = wi * xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }   // x1 = wd∘b recomputed (xin = b)
+    if (OP == FUSE_POST || OP == FUSE_POST_MAPPED) { xi = wi * xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }   // x1 = wd∘b recomputed (xin = b)
   }
   if (staged) {
     const int nch = (hi - start + 1) >> 1;
@@ -652,7 +658,8 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
-  if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
+  if (which == FUSE_POST_MAPPED) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST_MAPPED>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
+  else if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
   else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;

@@ -63,6 +63,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "strip") ctx->opt_strip = value;
   else if (k == "fuse") ctx->opt_fuse = value;
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
+  else if (k == "fuse_operands") ctx->opt_fuse_operands = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
@@ -290,6 +291,8 @@ static void level_free(mgs_level &L) {
   if (L.T) mgs_xfer_destroy(L.T);
   mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x); mgs_vec_destroy(L.wd);
   mgs_vec_destroy(L.hbuf);
+  if (L.val_wd) hipFree(L.val_wd);
+  if (L.col_agg) hipFree(L.col_agg);
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
@@ -575,11 +578,18 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo));
       return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, hi, nb);
     };
-    // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
-    MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, nullptr));
+    const bool operands = !halo && ctx->opt_fuse_operands && L.val_wd && L.col_agg;
+    // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b).  With the setup-time operand
+    // Â = A·diag(wd) this is the plain residual kernel on Â with x = b (one gather per entry).
+    if (operands) { mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false; MGS_TRY(mgs_launch_csr_op(&Ahat, MGS_OP_RESIDUAL, b, b, nullptr, 0.0, L.r->d)); }
+    else MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, nullptr));
     MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
+    if (operands) {   // columns pre-mapped to aggregates: (A·Pe)_i = Σ a_ij e_c[agg_j] gathers e_c directly
+      mgs_csr Amap = *L.A; Amap.col = L.col_agg; Amap.owns = false;
+      return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, b, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
+    }
     return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, b, L.T->agg, C.x->d, x, nullptr);
   }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
@@ -634,7 +644,13 @@ static int prepare_fused(mgs_hier *h) {
     if (L.A->rows != L.A->cols && !h->halo_fused) continue;
     if (!L.wd) MGS_TRY(mgs_vec_create(ctx, L.n, &L.wd));
     if (L.A->cols > L.A->rows && !L.hbuf) MGS_TRY(mgs_vec_create(ctx, L.A->cols - L.A->rows, &L.hbuf));
-    if (L.wd_omega != h->omega) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
+    const bool rescale = L.wd_omega != h->omega;
+    if (rescale) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
+    if (ctx->opt_fuse_operands && L.A->rows == L.A->cols) {      // derived CSR operands of the fused passes (same shape as A)
+      if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); }
+      else if (rescale) MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd));
+      if (!L.col_agg) { MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.col_agg)); drop_graph(h); }
+    }
   }
   return MGS_OK;
 }
@@ -654,8 +670,8 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
   const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
-  if (h->graph_fuse != ctx->opt_fuse) drop_graph(h);
-  h->graph_fuse = ctx->opt_fuse;
+  if (h->graph_fuse != ctx->opt_fuse * 2 + ctx->opt_fuse_operands) drop_graph(h);
+  h->graph_fuse = ctx->opt_fuse * 2 + ctx->opt_fuse_operands;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {

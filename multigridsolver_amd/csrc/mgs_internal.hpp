@@ -26,6 +26,7 @@ struct mgs_ctx {
   int opt_xcd_remap = 1;
   int opt_nontemporal = 0;  // non-temporal loads of val/col (measured: no gain with the slice kernel)
   int opt_fuse = 1;         // fused V-cycle passes on square levels
+  int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
@@ -84,6 +85,8 @@ struct mgs_level {
   mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
   mgs_vec *wd = nullptr;       // ω·dinv (fused passes)
   mgs_vec *hbuf = nullptr;     // halo payload of the fused passes (row shards)
+  double *val_wd = nullptr;    // setup-time operand of the fused pre pass: a_ij·wd_j, so A·(wd∘b) = Â·b needs one gather
+  int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -141,7 +144,8 @@ int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...);
 
 // ------------------------------------------------------------------ kernel launchers
 // (kernels_spmv.hip)
-enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2, FUSE_PRE = 3, FUSE_POST = 4 };
+enum { MGS_OP_SPMV = 0, MGS_OP_RESIDUAL = 1, MGS_OP_JACOBI = 2, FUSE_PRE = 3, FUSE_POST = 4,
+       FUSE_POST_MAPPED = 5 /* FUSE_POST whose column array already holds agg[col] */ };
 int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
                      const double *ec, double *out, double *out2);
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b,
@@ -150,6 +154,8 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
                             const double *dinv, double omega, double *out, int blk_lo, int blk_hi);
 int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
                            const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi);
+int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int *out);
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
 int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);

@@ -264,6 +264,18 @@ def test_full_multilevel_solve(ctx, mg, orc):
         ctx.set_option("fuse", 1)
     assert rel(y_unfused, ho.vcycle(b_np)) <= 1e-10
     assert rel(h.vcycle(b).numpy(), y_unfused) <= 1e-13
+    # fused passes with and without their setup-time operands (Â = A·diag(ωD⁻¹), agg[col]): equal to rounding;
+    # a new ω rescales Â
+    ctx.set_option("fuse_operands", 0)
+    try:
+        y_gather = h.vcycle(b).numpy()
+    finally:
+        ctx.set_option("fuse_operands", 1)
+    assert rel(y_gather, y_unfused) <= 1e-13
+    h.set_smoother(0.8, 1, 1); ho.set_smoother(0.8, 1, 1)
+    assert rel(h.vcycle(b).numpy(), ho.vcycle(b_np)) <= 1e-10
+    h.set_smoother(0.6, 1, 1); ho.set_smoother(0.6, 1, 1)
+    assert rel(h.vcycle(b).numpy(), y_unfused) <= 1e-13
     # graph replay and eager launches agree bit for bit
     ctx.set_option("graph", 0)
     try:
