@@ -265,12 +265,23 @@ def main():
     xs = ctx.vec(n).rand(seed=1)
     y = ctx.vec(n)
     dinv = A.diag_inv()
+    # plain CSR kernel first (12 B per entry streamed), then the shipped path: pattern-coded column index
+    # (mgs_csr_optimize: 8 B per entry + 1 B per row streamed; same products, same bits)
+    ctx.set_option("rowcode", 0)
+    A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
+    ms_spmv_csr = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=args.kernel_reps)
+    ctx.set_option("rowcode", 1)
+    A.optimize()
+    code = A.rowcode_info()
+    streamed = (8 * nnz + 21 * n + 4 * code["table_ints"] + 4 * (code["blocks"] + 1) * 2) if code["coded_blocks"] == code["blocks"] else None
     A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
     ms_spmv = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=args.kernel_reps)
     ms_res = A.time_kernel(mg.OP_RESIDUAL, xs, b=b, out=y, reps=args.kernel_reps)
     ms_jac = A.time_kernel(mg.OP_JACOBI, xs, b=b, dinv=dinv, out=y, reps=args.kernel_reps)
     gbps = lambda byts, ms: byts / (ms * 1e-3) / 1e9  # noqa: E731
     spmv_gbps = gbps(spmv_bytes(n, nnz), ms_spmv)
+    log(f"fine SpMV, plain CSR kernel {ms_spmv_csr:.3f} ms = {gbps(spmv_bytes(n, nnz), ms_spmv_csr):.0f} GB/s; pattern-coded: streams "
+        f"{(streamed or 0) / 1e9:.2f} GB of the {spmv_bytes(n, nnz) / 1e9:.2f} algorithmic GB")
     log(f"fine SpMV {ms_spmv:.3f} ms = {spmv_gbps:.0f} GB/s; residual {ms_res:.3f} ms = {gbps(residual_bytes(n, nnz), ms_res):.0f} GB/s; "
         f"jacobi {ms_jac:.3f} ms = {gbps(jacobi_bytes(n, nnz), ms_jac):.0f} GB/s")
     del xs, y
@@ -328,8 +339,14 @@ def main():
         "spmv_hbm_gbps": spmv_gbps,
         "roofline": {"bound": "hbm", "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": spmv_gbps / HBM_PEAK_GBPS,
                      "traffic": (pmc_traffic("spmv", N) or (None, None))[0], "traffic_source": (pmc_traffic("spmv", N) or (None, None))[1],
-                     "kernel": "csr_rowblock_slice_kernel<SPMV> (fine level)", "algorithmic_bytes_per_launch": spmv_bytes(n, nnz),
-                     "ms_per_launch": ms_spmv,
+                     "kernel": "csr_rowblock_coded_kernel<SPMV> (fine level; CSR SpMV with pattern-coded column index)",
+                     "algorithmic_bytes_per_launch": spmv_bytes(n, nnz), "ms_per_launch": ms_spmv,
+                     "note": "achieved = SURVEY §8d-d3 CSR bytes (12·nnz + 20·n + 4) / time; the kernel streams fewer bytes than that "
+                             "(column index rebuilt from a per-row-block pattern table), see streamed_*; csr_kernel = the same product "
+                             "with the plain 12 B/entry CSR kernel",
+                     "streamed_bytes_per_launch": streamed, "streamed_gbps": gbps(streamed, ms_spmv) if streamed else None,
+                     "streamed_frac": gbps(streamed, ms_spmv) / HBM_PEAK_GBPS if streamed else None,
+                     "csr_kernel": {"ms": ms_spmv_csr, "gbps": gbps(spmv_bytes(n, nnz), ms_spmv_csr), "frac": gbps(spmv_bytes(n, nnz), ms_spmv_csr) / HBM_PEAK_GBPS},
                      "other_kernels": {"residual": {"ms": ms_res, "gbps": gbps(residual_bytes(n, nnz), ms_res)},
                                        "jacobi": {"ms": ms_jac, "gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
                      "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9,

@@ -272,8 +272,16 @@ int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double 
  * row-block kernel, [4]=leading and [5]=trailing row blocks that read halo columns, [6]=1 if the
  * interior/boundary split is usable, [7]=1 if some block takes the long-row path.            */
 int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
+/* Builds the pattern code of A's column array (one byte per row + a small table per 256-row block) so the
+ * SpMV-shaped kernels stream 8 instead of 12 bytes per entry wherever rows repeat their shape (stencil-like
+ * operators); results stay bit-identical.  Hierarchies and the Krylov solvers call it for their operators; call
+ * it yourself before timing a bare mgs_spmv.  No reference counterpart (device-side layout choice).
+ * info: out[0] coded row blocks, out[1] row blocks, out[2] table ints, out[3] LDS table budget (ints). */
+int mgs_csr_optimize(mgs_csr *A);
+int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]);
+
 /* kernel-variant knobs for A/B measurements.  key: "spmv_variant", "xcd_remap", "nontemporal",
- * "graph", "strip", "fuse", "fuse_operands" (setup-time operands of the fused cycle passes,
+ * "graph", "strip", "fuse", "rowcode" (pattern-coded index, default 1), "fuse_operands" (setup-time operands of the fused cycle passes,
  * +12 B of HBM per matrix entry; default 1), "lds_pad", "blkptr".  Unknown key: MGS_ERR_INVALID. */
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);
 

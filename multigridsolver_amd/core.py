@@ -135,6 +135,14 @@ class Csr:
         keys = ["max_block_nnz", "max_row_len", "far_band", "lds_bytes", "halo_lo_blocks", "halo_hi_blocks", "halo_split_ok", "has_long_row_blocks"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def optimize(self):
+        """build the pattern code of the column array (mgs_csr_optimize); returns self"""
+        check(lib().mgs_csr_optimize(self.h), self.ctx.h); return self
+
+    def rowcode_info(self):
+        out = (C.c_int64 * 4)(); lib().mgs_csr_rowcode_info(self.h, out)
+        return dict(zip(["coded_blocks", "blocks", "table_ints", "table_budget"], [int(v) for v in out]))
+
     def download(self):
         rows, _ = self.shape; nnz = self.nnz
         rp = np.empty(rows + 1, dtype=np.int32); ci = np.empty(max(nnz, 1), dtype=np.int32); v = np.empty(max(nnz, 1))

@@ -325,6 +325,167 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Pattern-coded rows (DESIGN.md §4 "pattern-coded index").  Operators of PDE problems repeat a handful of row
+// shapes: the tuple (idx[k] − base(row))_k of a row — base(row) = row for the column array, agg[row] for the
+// aggregate-mapped column array of the fused post pass — takes 3 distinct values in a 256-row block of the
+// 7-point operator and a few dozen on the first Galerkin levels.  Setup dedupes the tuples per row block into a
+// small table (`tab`: pstart[npat] then the tuples) and stores one byte per ROW (`pid`); the kernel then streams
+// only the values (8 B per entry instead of 12) and rebuilds every index as base + tab[pstart[pid] + j] from LDS
+// (lanes of a wave mostly read the same table word: LDS broadcast).  Same products in the same order → the results
+// stay bit-identical to the CSR kernel.  Row blocks whose table would not pay (irregular rows) keep the index
+// array (block-uniform branch), so any matrix is handled.
+constexpr int CODE_NEG = (int)0x80000000;   // table word of a negative index (column not aggregated)
+
+template <int OP, int U>
+__global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
+    const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
+    const double *__restrict__ x /*gather source: x, or e_c for the post pass*/, const double *__restrict__ b /*b, or r for the post pass*/,
+    const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
+    const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr) {
+  extern __shared__ double lds_raw[];
+  constexpr bool POST = OP == FUSE_POST_MAPPED;
+  const int vb = map_block(bm, blockIdx.x);
+  if (vb < 0) return;
+  const int blk = bm.base + vb;
+  const int r0 = blk * RB;
+  const int r1 = min(r0 + RB, n);
+  const int tid = threadIdx.x;
+  const int lo = blkptr[blk], hi = blkptr[blk + 1];
+  const int t0 = tptr[blk], tlen = tptr[blk + 1] - t0;
+  double *__restrict__ vals = lds_raw;                                    // capv + 2 doubles
+  int *__restrict__ ints = reinterpret_cast<int *>(lds_raw + capv + 2);   // capi ints: the block's table, or its index slice
+  const int row = r0 + tid;
+  const int start = lo & ~1;
+  const int nent = hi - start;
+  const bool coded = tlen > 0 && tlen <= capi;
+  const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi);     // block-uniform
+  int ga = 0, ge = 0, base = row;
+  double bi = 0.0, di = 0.0, xi = 0.0, pei = 0.0;
+  if (row < r1) {
+    ga = rowptr[row]; ge = rowptr[row + 1];
+    if (OP != MGS_OP_SPMV) bi = b[row];
+    if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
+    if (POST) { di = dinv[row]; xi = di * xin[row]; base = agg[row]; pei = base >= 0 ? x[base] : 0.0; }
+  }
+  double s = 0.0;
+  if (staged) {
+    const int nch = (nent + 1) >> 1;
+    if (coded) {
+#pragma unroll 4
+      for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+      for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
+    } else {
+#pragma unroll 4
+      for (int c = tid; c < nch; c += RB) {
+        const int k = start + 2 * c;
+        *reinterpret_cast<int2_t *>(ints + 2 * c) = *reinterpret_cast<const int2_t *>(idx + k);
+        *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
+      }
+    }
+    __syncthreads();
+    if (row < r1 && ge > ga) {
+      const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
+      if (coded) {
+        const int ps = ints[pid[row]];
+        const int last = my_e - my_a - 1;
+        for (int k = my_a, j = 0; k < my_e; k += U, j += U) {
+          int oq[U]; double xv[U], vq[U];
+#pragma unroll
+          for (int q = 0; q < U; ++q) oq[q] = ints[ps + min(j + q, last)];   // past the row's end: the row's last index again
+#pragma unroll
+          for (int q = 0; q < U; ++q) xv[q] = (POST && oq[q] == CODE_NEG) ? 0.0 : x[base + oq[q]];
+#pragma unroll
+          for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+          for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+        }
+      } else {
+        for (int k = my_a; k < my_e; k += U) {
+          int cq[U]; double xv[U], vq[U];
+#pragma unroll
+          for (int q = 0; q < U; ++q) cq[q] = ints[min(k + q, lim)];
+#pragma unroll
+          for (int q = 0; q < U; ++q) xv[q] = (POST && cq[q] < 0) ? 0.0 : x[cq[q]];
+#pragma unroll
+          for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+          for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+        }
+      }
+    }
+  } else if (row < r1) {
+    // heavier-than-budget block: lane t walks row t straight from global memory, same ascending order
+    for (int k = ga; k < ge; ++k) { const int c = idx[k]; s += val[k] * ((POST && c < 0) ? 0.0 : x[c]); }
+  }
+  if (row < r1) {
+    if (OP == MGS_OP_SPMV) out[row] = s;
+    else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
+    else if (OP == MGS_OP_JACOBI) out[row] = xi + (omega * di) * (bi - s);
+    else out[row] = (xi + pei) + di * (bi - s);
+  }
+}
+
+// setup pass 1: per row block, elect representatives (smallest row of each distinct tuple), give every row the
+// rank of its representative (deterministic: order of first appearance), and size the block's table.  A block
+// whose table would exceed half of its index slice is left uncoded (size 0).
+__device__ __forceinline__ int code_off(int i, int base) { return i < 0 ? CODE_NEG : i - base; }
+__global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
+                                                            const int *__restrict__ base, unsigned char *__restrict__ pid,
+                                                            unsigned char *__restrict__ isrep, int *__restrict__ blk_ints) {
+  __shared__ int s_rep, s_ints, s_np;
+  const int blk = blockIdx.x, r0 = blk * RB, r1 = min(r0 + RB, n), tid = threadIdx.x, row = r0 + tid;
+  const bool valid = row < r1;
+  int a = 0, len = 0, bs = 0;
+  if (valid) { a = rowptr[row]; len = rowptr[row + 1] - a; bs = base ? base[row] : row; }
+  const int budget = (rowptr[r1] - rowptr[r0]) / 2 - 64;
+  bool assigned = !valid, rep = false, ok = true;
+  int mypid = 0;
+  if (tid == 0) { s_ints = 0; s_np = 0; }
+  for (int p = 0; p < RB; ++p) {
+    if (tid == 0) s_rep = 0x7fffffff;
+    __syncthreads();
+    if (!assigned) atomicMin(&s_rep, tid);
+    __syncthreads();
+    const int r = s_rep;
+    if (r == 0x7fffffff) break;
+    if (!assigned) {
+      bool same = true;
+      if (tid != r) {
+        const int rr = r0 + r, ra = rowptr[rr], rl = rowptr[rr + 1] - ra, rb = base ? base[rr] : rr;
+        same = rl == len;
+        for (int j = 0; same && j < len; ++j) same = code_off(idx[a + j], bs) == code_off(idx[ra + j], rb);
+      } else { rep = true; s_ints += len; s_np = p + 1; }
+      if (same) { assigned = true; mypid = p; }
+    }
+    __syncthreads();
+    if (s_np + s_ints > budget) { ok = false; break; }
+  }
+  if (valid) { pid[row] = ok ? (unsigned char)mypid : 0; isrep[row] = (ok && rep) ? 1 : 0; }
+  if (tid == 0) blk_ints[blk] = ok ? s_np + s_ints : 0;
+}
+// setup pass 2: write the tables (pstart[npat], then the tuples in representative order)
+__global__ __launch_bounds__(RB) void rowcode_fill_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
+                                                          const int *__restrict__ base, const unsigned char *__restrict__ pid,
+                                                          const unsigned char *__restrict__ isrep, const int *__restrict__ tptr,
+                                                          int *__restrict__ tab) {
+  __shared__ int plen[RB], pstart[RB];
+  const int blk = blockIdx.x, r0 = blk * RB, r1 = min(r0 + RB, n), tid = threadIdx.x, row = r0 + tid;
+  const int t0 = tptr[blk];
+  if (tptr[blk + 1] == t0) return;
+  const bool rep = row < r1 && isrep[row];
+  int a = 0, len = 0, bs = 0, p = 0;
+  if (rep) { a = rowptr[row]; len = rowptr[row + 1] - a; bs = base ? base[row] : row; p = pid[row]; plen[p] = len; }
+  const int np = __syncthreads_count(rep);
+  if (tid == 0) { int acc = np; for (int q = 0; q < np; ++q) { pstart[q] = acc; acc += plen[q]; } }
+  __syncthreads();
+  if (rep) {
+    tab[t0 + p] = pstart[p];
+    for (int j = 0; j < len; ++j) tab[t0 + pstart[p] + j] = code_off(idx[a + j], bs);
+  }
+}
+
 // Variant D: variant B with ONE WAVE per workgroup (64 rows, ~5 KB of LDS).  No workgroup barrier at
 // all — a wave's LDS writes are ordered before its own reads — so every wave streams, gathers and
 // stores at its own pace and the CU always has waves in each phase.  Four consecutive 64-row groups of
@@ -626,6 +787,92 @@ int mgs_plan_csr(mgs_csr *A) {
   return MGS_OK;
 }
 
+// Builds the pattern code of the index array `idx` (CSR-shaped like rowptr; base = nullptr: offsets from the row).
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, mgs_rowcode **out) {
+  *out = nullptr;
+  if (n <= 0) return MGS_OK;
+  const int nblocks = (n + RB - 1) / RB;
+  mgs_rowcode *c = new mgs_rowcode();
+  c->nblocks = nblocks;
+  unsigned char *isrep = nullptr;
+  int *ints = nullptr;
+  int rc = mgs_dev_alloc(ctx, &c->pid, (size_t)n);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &isrep, (size_t)n);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &ints, (size_t)nblocks + 1);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &c->tptr, (size_t)nblocks + 1);
+  std::vector<int> h((size_t)nblocks + 1, 0);
+  if (rc == MGS_OK) {
+    hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)nblocks + 1), ctx->stream);
+    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, c->pid, isrep, ints);
+    hipMemcpyAsync(h.data(), ints, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 1 failed");
+  }
+  if (rc == MGS_OK) {
+    int64_t total = 0;
+    std::vector<int> sizes;
+    for (int q = 0; q < nblocks; ++q) { const int v = h[q]; h[q] = (int)total; total += v; if (v) { c->coded_blocks++; sizes.push_back(v); } }
+    h[nblocks] = (int)total;
+    c->tab_total = total;
+    if (total >= 0x7fffffffLL) c->coded_blocks = 0;      // cannot index the table with 32 bits: leave the matrix uncoded
+    if (c->coded_blocks) {
+      // table budget in LDS: covers 98.5 % of the coded blocks (the rest walk their rows from global memory)
+      std::sort(sizes.begin(), sizes.end());
+      c->tab_max = sizes.back();
+      c->tab_cap = sizes[(size_t)((sizes.size() - 1) * 0.985)];
+      hipMemcpyAsync(c->tptr, h.data(), sizeof(int) * ((size_t)nblocks + 1), hipMemcpyHostToDevice, ctx->stream);
+      rc = mgs_dev_alloc(ctx, &c->tab, (size_t)total + 4);
+      if (rc == MGS_OK) {
+        hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, c->pid, isrep, c->tptr, c->tab);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 2 failed");
+      }
+    }
+  }
+  if (isrep) hipFree(isrep);
+  if (ints) hipFree(ints);
+  if (rc != MGS_OK || !c->coded_blocks) { mgs_free_rowcode(c); c = nullptr; }
+  *out = c;
+  return rc;
+}
+void mgs_free_rowcode(mgs_rowcode *c) {
+  if (!c) return;
+  if (c->pid) hipFree(c->pid);
+  if (c->tptr) hipFree(c->tptr);
+  if (c->tab) hipFree(c->tab);
+  delete c;
+}
+
+// true when the coded kernel serves this operator (square or sharded; short rows; code present and worth it)
+static bool use_rowcode(const mgs_csr *A, const mgs_rowcode *c) {
+  return c && A->ctx->opt_rowcode && A->blkptr && A->lds_cap > 0 && A->max_row_len <= 64 &&
+         (double)c->coded_blocks >= 0.5 * c->nblocks;
+}
+// op ∈ {SPMV, RESIDUAL, JACOBI, FUSE_POST_MAPPED}; for the post pass: x = e_c, b = r, dinv = wd, xin = b, idx = agg[col]
+static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const int *idx, const double *x, const double *b, const double *dinv,
+                        double omega, const double *xin, const int *agg, double *out, dim3 grid, BlockMap bm) {
+  mgs_ctx *ctx = A->ctx;
+  const int capv = A->lds_cap;
+  // nearly everything coded: LDS holds values + tables only (8 B per entry → more workgroups per CU); otherwise
+  // the integer region must also fit the index slice of the uncoded blocks
+  const bool lean = (double)c->coded_blocks >= 0.985 * c->nblocks;
+  const int capi = lean ? std::max(c->tab_cap, 64) : std::max(c->tab_cap, capv + 2);
+  const size_t lds = (size_t)(capv + 2) * 8 + (size_t)capi * 4 + 16 + (size_t)ctx->opt_lds_pad;
+  const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
+  const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
+#define C_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
+                                     c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, capi, bm, A->blkptr)
+#define CU_(O) do { if (u == 4) C_(O, 4); else if (u == 7) C_(O, 7); else C_(O, 8); } while (0)
+  switch (op) {
+    case MGS_OP_SPMV: CU_(MGS_OP_SPMV); break;
+    case MGS_OP_RESIDUAL: CU_(MGS_OP_RESIDUAL); break;
+    case MGS_OP_JACOBI: CU_(MGS_OP_JACOBI); break;
+    default: CU_(FUSE_POST_MAPPED); break;
+  }
+#undef CU_
+#undef C_
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,
                       double omega, double *out) {
   return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, (A->rows + RB - 1) / RB);
@@ -658,6 +905,8 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
+  if (which == FUSE_POST_MAPPED && use_rowcode(A, A->code))      // A is the view whose col/code are the aggregate-mapped ones
+    return launch_coded(A, A->code, FUSE_POST_MAPPED, A->col, ec, bvec, wd, 0.0, xin, agg, out, grid, bm);
   if (which == FUSE_POST_MAPPED) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST_MAPPED>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
   else if (which == FUSE_PRE) hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_PRE>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
   else hipLaunchKernelGGL((csr_rowblock_fused_kernel<FUSE_POST>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, wd, bvec, xin, agg, ec, out, out2, cap, bm, hv, A->ctx->opt_blkptr ? A->blkptr : nullptr);
@@ -730,6 +979,8 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
     return MGS_OK;
   }
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  if (ctx->opt_spmv_variant == 0 && !ctx->opt_nontemporal && use_rowcode(A, A->code))
+    return launch_coded(A, A->code, op, A->col, x, b, dinv, omega, nullptr, nullptr, out, grid, bm);
   size_t lds = sizeof(double) * (size_t)(cap > 0 ? cap : 1);
   // lanes per row of the long-row path: next power of two ≥ mean row length, in [4,64]
   double mean = A->rows ? (double)A->nnz / A->rows : 1.0;

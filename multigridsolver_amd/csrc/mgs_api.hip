@@ -64,6 +64,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "fuse") ctx->opt_fuse = value;
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
   else if (k == "fuse_operands") ctx->opt_fuse_operands = value;
+  else if (k == "rowcode") ctx->opt_rowcode = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
@@ -136,7 +137,18 @@ int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
   if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }
   if (A->blkptr) hipFree(A->blkptr);
+  mgs_free_rowcode(A->code);
   delete A;
+  return MGS_OK;
+}
+int mgs_csr_optimize(mgs_csr *A) {
+  if (!A || A->code_tried || !A->ctx->opt_rowcode || A->rows == 0 || A->nnz == 0) return MGS_OK;
+  A->code_tried = true;
+  return mgs_build_rowcode(A->ctx, A->rows, A->rowptr, A->col, nullptr, &A->code);
+}
+int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]) {
+  out[0] = A->code ? A->code->coded_blocks : 0; out[1] = A->code ? A->code->nblocks : (A->rows + 255) / 256;
+  out[2] = A->code ? A->code->tab_total : 0; out[3] = A->code ? A->code->tab_cap : 0;
   return MGS_OK;
 }
 int mgs_csr_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out) { return k_poisson3d(ctx, N, plane_lo, plane_hi, local_cols, out); }
@@ -293,6 +305,7 @@ static void level_free(mgs_level &L) {
   mgs_vec_destroy(L.hbuf);
   if (L.val_wd) hipFree(L.val_wd);
   if (L.col_agg) hipFree(L.col_agg);
+  mgs_free_rowcode(L.code_agg);
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
@@ -587,7 +600,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
     if (operands) {   // columns pre-mapped to aggregates: (A·Pe)_i = Σ a_ij e_c[agg_j] gathers e_c directly
-      mgs_csr Amap = *L.A; Amap.col = L.col_agg; Amap.owns = false;
+      mgs_csr Amap = *L.A; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
       return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, b, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
     }
     return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, b, L.T->agg, C.x->d, x, nullptr);
@@ -629,6 +642,9 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 // wd = ω·dinv of every level that can run the fused passes; allocated and filled outside any stream capture
 static int prepare_fused(mgs_hier *h) {
   mgs_ctx *ctx = h->ctx;
+  if (ctx->opt_rowcode)      // pattern codes of the level operators (a cache attached to the matrices)
+    for (mgs_level &L : h->lev)
+      if (!L.A->code_tried) { MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(L.A))); drop_graph(h); }
   for (int l = 1; l <= h->kcycle_levels && l < (int)h->lev.size() - 1; ++l) {
     mgs_level &L = h->lev[l];
     if (L.kscal) continue;
@@ -649,7 +665,10 @@ static int prepare_fused(mgs_hier *h) {
     if (ctx->opt_fuse_operands && L.A->rows == L.A->cols) {      // derived CSR operands of the fused passes (same shape as A)
       if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); }
       else if (rescale) MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd));
-      if (!L.col_agg) { MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.col_agg)); drop_graph(h); }
+      if (!L.col_agg) {
+        MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.col_agg)); drop_graph(h);
+        if (ctx->opt_rowcode) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, &L.code_agg));
+      }
     }
   }
   return MGS_OK;
@@ -670,8 +689,9 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
   const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
-  if (h->graph_fuse != ctx->opt_fuse * 2 + ctx->opt_fuse_operands) drop_graph(h);
-  h->graph_fuse = ctx->opt_fuse * 2 + ctx->opt_fuse_operands;
+  const int gkey = ctx->opt_fuse * 4 + ctx->opt_fuse_operands * 2 + ctx->opt_rowcode;
+  if (h->graph_fuse != gkey) drop_graph(h);
+  h->graph_fuse = gkey;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {
@@ -707,6 +727,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
 int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int *max_iter, double *tol, int *status) {
   mgs_ctx *ctx = A->ctx;
   MGS_CHECK(ctx, max_iter && tol && status, MGS_ERR_INVALID, "mgs_bicgstab: NULL out parameter");
+  MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(A)));
   const int n = A->rows, next = A->cols > n ? A->cols : n;
   MGS_CHECK(ctx, x->n >= n && b->n >= n, MGS_ERR_INVALID, "mgs_bicgstab: vectors shorter than %d", n);
   mgs_vec *p = 0, *phat = 0, *s = 0, *shat = 0, *t = 0, *v = 0, *r = 0, *rt = 0, *xe = 0;
@@ -774,6 +795,7 @@ int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int re
   mgs_ctx *ctx = A->ctx;
   MGS_CHECK(ctx, max_iter && tol && status && restart >= 1 && restart <= 64, MGS_ERR_INVALID, "mgs_fgcr: bad arguments");
   MGS_CHECK(ctx, A->rows == A->cols && x->n >= A->rows && b->n >= A->rows, MGS_ERR_INVALID, "mgs_fgcr: square unsharded operator required");
+  MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(A)));
   const int n = A->rows;
   struct Guard { std::vector<mgs_vec *> vs; ~Guard() { for (auto q : vs) mgs_vec_destroy(q); } } guard;
   auto mk = [&](mgs_vec **q) -> int { int rc = mgs_vec_create(ctx, n, q); if (rc == MGS_OK) guard.vs.push_back(*q); return rc; };

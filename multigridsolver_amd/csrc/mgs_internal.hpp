@@ -29,11 +29,22 @@ struct mgs_ctx {
   int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_rowcode = 1;   // pattern-coded index (8 B per entry streamed instead of 12 where rows repeat their shape)
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   mgs_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+};
+
+// pattern code of a CSR-shaped index array (kernels_spmv.hip): one byte per row + a small table per row block
+struct mgs_rowcode {
+  unsigned char *pid = nullptr;  // n: the row's tuple within its row block's table
+  int *tptr = nullptr;           // nblocks+1: table slice of each row block in tab (empty: block keeps its index array)
+  int *tab = nullptr;            // per coded block: pstart[npat], then the offset tuples
+  int tab_max = 0, tab_cap = 0;  // largest table / LDS budget covering 98.5 % of the coded blocks (ints)
+  int coded_blocks = 0, nblocks = 0;
+  int64_t tab_total = 0;
 };
 
 struct mgs_csr {
@@ -54,6 +65,8 @@ struct mgs_csr {
   int lds_cap = 0;  // entries staged per block
   int max_block_nnz = 0;
   int max_wave_nnz = 0;   // max entries of a 64-row group
+  mgs_rowcode *code = nullptr;   // pattern code of col (mgs_csr_optimize; owned unless this is a view)
+  bool code_tried = false;
 };
 
 struct mgs_vec {
@@ -87,6 +100,7 @@ struct mgs_level {
   mgs_vec *hbuf = nullptr;     // halo payload of the fused passes (row shards)
   double *val_wd = nullptr;    // setup-time operand of the fused pre pass: a_ij·wd_j, so A·(wd∘b) = Â·b needs one gather
   int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
+  mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -159,6 +173,8 @@ int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int *out);
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
 int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, mgs_rowcode **out);
+void mgs_free_rowcode(mgs_rowcode *c);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc);

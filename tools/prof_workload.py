@@ -15,6 +15,7 @@ n = N ** 3
 A = ctx.poisson3d(N)
 h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 1024, 32).finalize()
 x = ctx.vec(n).rand(seed=1); b = ctx.vec(n).rand(seed=0); y = ctx.vec(n); dinv = A.diag_inv()
+A.optimize()                 # pattern code of the column array (what hierarchies and solvers do for their operators)
 ctx.set_option("graph", 0)   # eager launches so every kernel shows up as its own dispatch
 # calibration: axpbypcz_kernel z = 2x + 3b + 0.5z reads 24n bytes and writes 8n bytes with 8-byte lanes
 # (a kernel the V-cycle itself never launches, so every dispatch of it is a calibration launch)

@@ -31,11 +31,11 @@ def short(name):
 
 def classify(name):
     s = short(name)
-    for pre in ("csr_rowblock_kernel<", "csr_rowblock_slice_kernel<"):
+    for pre in ("csr_rowblock_kernel<", "csr_rowblock_slice_kernel<", "csr_rowblock_coded_kernel<"):
         if s.startswith(pre):
-            return {"0": "spmv", "1": "residual", "2": "jacobi"}.get(s[len(pre)], None)
+            return {"0": "spmv", "1": "residual", "2": "jacobi", "5": "fused_post"}.get(s[len(pre)], None)
     if s.startswith("csr_rowblock_fused_kernel<3"): return "fused_pre"
-    if s.startswith("csr_rowblock_fused_kernel<4"): return "fused_post"
+    if s.startswith("csr_rowblock_fused_kernel<4") or s.startswith("csr_rowblock_fused_kernel<5"): return "fused_post"
     if s.startswith("axpbypcz_kernel"): return "axpby(calibration)"
     return None
 
