@@ -278,6 +278,10 @@ int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
  * it yourself before timing a bare mgs_spmv.  No reference counterpart (device-side layout choice).
  * info: out[0] coded row blocks, out[1] row blocks, out[2] table ints, out[3] LDS table budget (ints). */
 int mgs_csr_optimize(mgs_csr *A);
+/* which form of the fused passes level `level` runs (filled in by the first cycle): out[0] row blocks, out[1]/out[2]
+ * setup-time operands present (scaled values / aggregate-mapped columns), out[3..5] coded row blocks of the column
+ * array, of its halo-tagged copy (row shards) and of the aggregate-mapped array. */
+int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]);
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements.  key: "spmv_variant", "xcd_remap", "nontemporal",

@@ -98,12 +98,13 @@ __global__ void scale_vals_kernel(int n, const int *__restrict__ rowptr, const i
                                   const double *__restrict__ wd, double *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = val[k] * wd[col[k]];
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) { const int c = col[k]; out[k] = c < n ? val[k] * wd[c] : val[k]; }   // halo column: the payload is x1 itself
 }
-__global__ void map_cols_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ agg, int *__restrict__ out) {
+__global__ void map_cols_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ agg, int n_coarse,
+                                int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = agg[col[k]];
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) { const int c = col[k]; out[k] = c < n ? agg[c] : n_coarse + (c - n); }   // halo column: payload slot
 }
 
 // halo payloads of the fused passes on row shards: the peer needs x1 = wd∘b resp. (Pe) = e_c[agg] of my rows
@@ -434,8 +435,8 @@ int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out) 
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
-int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int *out) {
-  if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, agg, out);
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int *out) {
+  if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, agg, n_coarse, out);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

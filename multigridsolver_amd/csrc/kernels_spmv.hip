@@ -336,14 +336,18 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
 // stay bit-identical to the CSR kernel.  Row blocks whose table would not pay (irregular rows) keep the index
 // array (block-uniform branch), so any matrix is handled.
 constexpr int CODE_NEG = (int)0x80000000;   // table word of a negative index (column not aggregated)
+// Row shards: an index ≥ split addresses the halo payload hv[index − split].  Its table word is tagged and holds
+// slot − row (constant along a plane boundary, where index − base is not): word = CODE_HALO + (slot − row).
+constexpr int CODE_HALO = 0x60000000, CODE_HALO_LO = 0x50000000, CODE_OFF_MAX = 0x40000000;
 
-template <int OP, int U>
+template <int OP, int U, bool HALO>
 __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x /*gather source: x, or e_c for the post pass*/, const double *__restrict__ b /*b, or r for the post pass*/,
     const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
-    const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr) {
+    const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,
+    const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int vb = map_block(bm, blockIdx.x);
@@ -395,7 +399,10 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
 #pragma unroll
           for (int q = 0; q < U; ++q) oq[q] = ints[ps + min(j + q, last)];   // past the row's end: the row's last index again
 #pragma unroll
-          for (int q = 0; q < U; ++q) xv[q] = (POST && oq[q] == CODE_NEG) ? 0.0 : x[base + oq[q]];
+          for (int q = 0; q < U; ++q) {
+            if (HALO && oq[q] >= CODE_HALO_LO) xv[q] = hv[row + (oq[q] - CODE_HALO)];
+            else xv[q] = (POST && oq[q] == CODE_NEG) ? 0.0 : x[base + oq[q]];
+          }
 #pragma unroll
           for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
 #pragma unroll
@@ -407,7 +414,10 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
 #pragma unroll
           for (int q = 0; q < U; ++q) cq[q] = ints[min(k + q, lim)];
 #pragma unroll
-          for (int q = 0; q < U; ++q) xv[q] = (POST && cq[q] < 0) ? 0.0 : x[cq[q]];
+          for (int q = 0; q < U; ++q) {
+            if (HALO && cq[q] >= split) xv[q] = hv[cq[q] - split];
+            else xv[q] = (POST && cq[q] < 0) ? 0.0 : x[cq[q]];
+          }
 #pragma unroll
           for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
 #pragma unroll
@@ -417,7 +427,10 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
     }
   } else if (row < r1) {
     // heavier-than-budget block: lane t walks row t straight from global memory, same ascending order
-    for (int k = ga; k < ge; ++k) { const int c = idx[k]; s += val[k] * ((POST && c < 0) ? 0.0 : x[c]); }
+    for (int k = ga; k < ge; ++k) {
+      const int c = idx[k];
+      s += val[k] * ((HALO && c >= split) ? hv[c - split] : ((POST && c < 0) ? 0.0 : x[c]));
+    }
   }
   if (row < r1) {
     if (OP == MGS_OP_SPMV) out[row] = s;
@@ -430,11 +443,18 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
 // setup pass 1: per row block, elect representatives (smallest row of each distinct tuple), give every row the
 // rank of its representative (deterministic: order of first appearance), and size the block's table.  A block
 // whose table would exceed half of its index slice is left uncoded (size 0).
-__device__ __forceinline__ int code_off(int i, int base) { return i < 0 ? CODE_NEG : i - base; }
+// (a word outside the representable ranges makes the block uncodable: returns CODE_BAD)
+constexpr int CODE_BAD = 0x7fffffff;
+__device__ __forceinline__ int code_off(int i, int base, int row, int split) {
+  if (i < 0) return CODE_NEG;
+  if (i >= split) { const int d = (i - split) - row; return (d > -0x10000000 && d < 0x10000000) ? CODE_HALO + d : CODE_BAD; }
+  const int o = i - base;
+  return (o > -CODE_OFF_MAX && o < CODE_OFF_MAX) ? o : CODE_BAD;
+}
 __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
-                                                            const int *__restrict__ base, unsigned char *__restrict__ pid,
+                                                            const int *__restrict__ base, int split, unsigned char *__restrict__ pid,
                                                             unsigned char *__restrict__ isrep, int *__restrict__ blk_ints) {
-  __shared__ int s_rep, s_ints, s_np;
+  __shared__ int s_rep, s_ints, s_np, s_bad;
   const int blk = blockIdx.x, r0 = blk * RB, r1 = min(r0 + RB, n), tid = threadIdx.x, row = r0 + tid;
   const bool valid = row < r1;
   int a = 0, len = 0, bs = 0;
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__
   const int budget = (rowptr[r1] - rowptr[r0]) / 2 - 64;
   bool assigned = !valid, rep = false, ok = true;
   int mypid = 0;
-  if (tid == 0) { s_ints = 0; s_np = 0; }
+  if (tid == 0) { s_ints = 0; s_np = 0; s_bad = 0; }
   for (int p = 0; p < RB; ++p) {
     if (tid == 0) s_rep = 0x7fffffff;
     __syncthreads();
@@ -455,19 +475,22 @@ __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__
       if (tid != r) {
         const int rr = r0 + r, ra = rowptr[rr], rl = rowptr[rr + 1] - ra, rb = base ? base[rr] : rr;
         same = rl == len;
-        for (int j = 0; same && j < len; ++j) same = code_off(idx[a + j], bs) == code_off(idx[ra + j], rb);
-      } else { rep = true; s_ints += len; s_np = p + 1; }
+        for (int j = 0; same && j < len; ++j) same = code_off(idx[a + j], bs, row, split) == code_off(idx[ra + j], rb, rr, split);
+      } else {
+        rep = true; s_ints += len; s_np = p + 1;
+        for (int j = 0; j < len; ++j) if (code_off(idx[a + j], bs, row, split) == CODE_BAD) s_bad = 1;
+      }
       if (same) { assigned = true; mypid = p; }
     }
     __syncthreads();
-    if (s_np + s_ints > budget) { ok = false; break; }
+    if (s_np + s_ints > budget || s_bad) { ok = false; break; }
   }
   if (valid) { pid[row] = ok ? (unsigned char)mypid : 0; isrep[row] = (ok && rep) ? 1 : 0; }
   if (tid == 0) blk_ints[blk] = ok ? s_np + s_ints : 0;
 }
 // setup pass 2: write the tables (pstart[npat], then the tuples in representative order)
 __global__ __launch_bounds__(RB) void rowcode_fill_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
-                                                          const int *__restrict__ base, const unsigned char *__restrict__ pid,
+                                                          const int *__restrict__ base, int split, const unsigned char *__restrict__ pid,
                                                           const unsigned char *__restrict__ isrep, const int *__restrict__ tptr,
                                                           int *__restrict__ tab) {
   __shared__ int plen[RB], pstart[RB];
@@ -482,7 +505,7 @@ __global__ __launch_bounds__(RB) void rowcode_fill_kernel(int n, const int *__re
   __syncthreads();
   if (rep) {
     tab[t0 + p] = pstart[p];
-    for (int j = 0; j < len; ++j) tab[t0 + pstart[p] + j] = code_off(idx[a + j], bs);
+    for (int j = 0; j < len; ++j) tab[t0 + pstart[p] + j] = code_off(idx[a + j], bs, row, split);
   }
 }
 
@@ -787,8 +810,9 @@ int mgs_plan_csr(mgs_csr *A) {
   return MGS_OK;
 }
 
-// Builds the pattern code of the index array `idx` (CSR-shaped like rowptr; base = nullptr: offsets from the row).
-int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, mgs_rowcode **out) {
+// Builds the pattern code of the index array `idx` (CSR-shaped like rowptr; base = nullptr: offsets from the row;
+// indices >= split address the halo payload of a row shard and are coded as slot − row).
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out) {
   *out = nullptr;
   if (n <= 0) return MGS_OK;
   const int nblocks = (n + RB - 1) / RB;
@@ -803,7 +827,7 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
   std::vector<int> h((size_t)nblocks + 1, 0);
   if (rc == MGS_OK) {
     hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)nblocks + 1), ctx->stream);
-    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, c->pid, isrep, ints);
+    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, ints);
     hipMemcpyAsync(h.data(), ints, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 1 failed");
   }
@@ -822,7 +846,7 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
       hipMemcpyAsync(c->tptr, h.data(), sizeof(int) * ((size_t)nblocks + 1), hipMemcpyHostToDevice, ctx->stream);
       rc = mgs_dev_alloc(ctx, &c->tab, (size_t)total + 4);
       if (rc == MGS_OK) {
-        hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, c->pid, isrep, c->tptr, c->tab);
+        hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, c->tptr, c->tab);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 2 failed");
       }
     }
@@ -848,7 +872,8 @@ static bool use_rowcode(const mgs_csr *A, const mgs_rowcode *c) {
 }
 // op ∈ {SPMV, RESIDUAL, JACOBI, FUSE_POST_MAPPED}; for the post pass: x = e_c, b = r, dinv = wd, xin = b, idx = agg[col]
 static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const int *idx, const double *x, const double *b, const double *dinv,
-                        double omega, const double *xin, const int *agg, double *out, dim3 grid, BlockMap bm) {
+                        double omega, const double *xin, const int *agg, double *out, dim3 grid, BlockMap bm,
+                        const double *hv = nullptr, int split = 0x7fffffff) {
   mgs_ctx *ctx = A->ctx;
   const int capv = A->lds_cap;
   // nearly everything coded: LDS holds values + tables only (8 B per entry → more workgroups per CU); otherwise
@@ -858,9 +883,10 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const size_t lds = (size_t)(capv + 2) * 8 + (size_t)capi * 4 + 16 + (size_t)ctx->opt_lds_pad;
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
-#define C_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
-                                     c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, capi, bm, A->blkptr)
-#define CU_(O) do { if (u == 4) C_(O, 4); else if (u == 7) C_(O, 7); else C_(O, 8); } while (0)
+#define C_(O, UU, H) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
+                                        c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, capi, bm, A->blkptr, hv, split)
+#define CH_(O, UU) do { if (hv) C_(O, UU, true); else C_(O, UU, false); } while (0)
+#define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)
   switch (op) {
     case MGS_OP_SPMV: CU_(MGS_OP_SPMV); break;
     case MGS_OP_RESIDUAL: CU_(MGS_OP_RESIDUAL); break;
@@ -868,9 +894,41 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
     default: CU_(FUSE_POST_MAPPED); break;
   }
 #undef CU_
+#undef CH_
 #undef C_
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
+}
+
+bool mgs_rowcode_usable(const mgs_csr *A) { return use_rowcode(A, A->code); }
+
+// workgroup → row-block map of a launch over the row blocks [blk_lo, blk_hi) (XCD-contiguous, strip-major for far bands)
+static dim3 plan_block_map(const mgs_csr *A, int blk_lo, int blk_hi, BlockMap &bm) {
+  mgs_ctx *ctx = A->ctx;
+  bm.base = blk_lo; bm.nblocks = blk_hi - blk_lo;
+  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
+  bm.chunk = (bm.nblocks + 7) / 8;
+  bm.D = 0; bm.S = 0; bm.P = 0;
+  int per_xcd = bm.chunk;
+  if (bm.remap && ctx->opt_strip != 0) {
+    const int D = (A->far_band + RB - 1) / RB;
+    if (D >= 512 && bm.chunk >= 2 * D) {
+      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
+      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+    }
+  }
+  return dim3(bm.remap ? per_xcd * 8 : bm.nblocks);
+}
+
+// The coded kernel on the row blocks [blk_lo, blk_hi) of the view A (A->col = the coded index array, A->code its
+// code); hv/split: halo payload of a row shard (nullptr / INT_MAX: none).  Caller checks mgs_rowcode_usable(A).
+int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
+                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi) {
+  if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
+  if (!use_rowcode(A, A->code)) return MGS_ERR_STATE;
+  BlockMap bm;
+  const dim3 grid = plan_block_map(A, blk_lo, blk_hi, bm);
+  return launch_coded(A, A->code, op, A->col, x, b, dinv, omega, xin, agg, out, grid, bm, hv, hv ? split : 0x7fffffff);
 }
 
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,

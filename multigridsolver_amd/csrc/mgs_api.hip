@@ -144,7 +144,7 @@ int mgs_csr_destroy(mgs_csr *A) {
 int mgs_csr_optimize(mgs_csr *A) {
   if (!A || A->code_tried || !A->ctx->opt_rowcode || A->rows == 0 || A->nnz == 0) return MGS_OK;
   A->code_tried = true;
-  return mgs_build_rowcode(A->ctx, A->rows, A->rowptr, A->col, nullptr, &A->code);
+  return mgs_build_rowcode(A->ctx, A->rows, A->rowptr, A->col, nullptr, 0x7fffffff, &A->code);
 }
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]) {
   out[0] = A->code ? A->code->coded_blocks : 0; out[1] = A->code ? A->code->nblocks : (A->rows + 255) / 256;
@@ -306,6 +306,7 @@ static void level_free(mgs_level &L) {
   if (L.val_wd) hipFree(L.val_wd);
   if (L.col_agg) hipFree(L.col_agg);
   mgs_free_rowcode(L.code_agg);
+  mgs_free_rowcode(L.code_pre);
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
@@ -453,6 +454,15 @@ int mgs_hier_finalize(mgs_hier *h) {
   return MGS_OK;
 }
 
+int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]) {
+  MGS_CHECK(h->ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_fused_info: level %d out of range", level);
+  const mgs_level &L = h->lev[level];
+  auto coded = [](const mgs_rowcode *c) -> int64_t { return c ? c->coded_blocks : 0; };
+  out[0] = (L.A->rows + 255) / 256; out[1] = L.val_wd != nullptr; out[2] = L.col_agg != nullptr;
+  out[3] = coded(L.A->code); out[4] = coded(L.code_pre); out[5] = coded(L.code_agg);
+  return MGS_OK;
+}
+
 int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
   // algorithmic bytes of the kernels one zero-guess cycle actually launches.
   // Every level starts from x = 0: the first pre-sweep is the 24n-byte (ωD⁻¹)b kernel, not a
@@ -591,18 +601,33 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo));
       return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, hi, nb);
     };
-    const bool operands = !halo && ctx->opt_fuse_operands && L.val_wd && L.col_agg;
-    // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b).  With the setup-time operand
-    // Â = A·diag(wd) this is the plain residual kernel on Â with x = b (one gather per entry).
-    if (operands) { mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false; MGS_TRY(mgs_launch_csr_op(&Ahat, MGS_OP_RESIDUAL, b, b, nullptr, 0.0, L.r->d)); }
+    // Setup-time operands: Â = A·diag(wd) makes the pre pass the plain residual kernel with x = b (one gather per
+    // entry), col_agg = agg[col] lets the post pass gather e_c directly.  On a shard the halo columns read the
+    // payload (x1 resp. Pe of the peers' rows) and only the pattern-coded kernel knows that split.
+    mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false; if (halo) Ahat.code = L.code_pre;
+    mgs_csr Amap = *L.A; Amap.val = L.A->val; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
+    const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
+                          (!halo || (mgs_rowcode_usable(&Ahat) && mgs_rowcode_usable(&Amap)));
+    auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
+                          const double *dv, const double *xin, const int *agg, double *out, int split) -> int {
+      int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
+      if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
+      if (L.A->halo_split_ok) MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, lo, hi));
+      rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 1);
+      if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (end) failed at level %d (%d)", l, rc);
+      if (!L.A->halo_split_ok) return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, 0, nb);
+      MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, 0, lo));
+      return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, hi, nb);
+    };
+    // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
+    if (operands && halo) MGS_TRY(coded_pass(&Ahat, MGS_OP_RESIDUAL, 0, L.wd->d, b, b, b, nullptr, nullptr, nullptr, L.r->d, L.A->rows));
+    else if (operands) MGS_TRY(mgs_launch_csr_op(&Ahat, MGS_OP_RESIDUAL, b, b, nullptr, 0.0, L.r->d));
     else MGS_TRY(fused_pass(FUSE_PRE, 0, L.wd->d, b, b, nullptr, nullptr, nullptr, L.r->d, nullptr));
     MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, L.r->d, C.b->d));
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
-    if (operands) {   // columns pre-mapped to aggregates: (A·Pe)_i = Σ a_ij e_c[agg_j] gathers e_c directly
-      mgs_csr Amap = *L.A; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
-      return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, b, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
-    }
+    if (operands && halo) return coded_pass(&Amap, FUSE_POST_MAPPED, 1, C.x->d, L.T->agg, C.x->d, L.r->d, L.wd->d, b, L.T->agg, x, L.T->n_coarse);
+    if (operands) return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, b, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
     return fused_pass(FUSE_POST, 1, C.x->d, L.T->agg, L.r->d, b, L.T->agg, C.x->d, x, nullptr);
   }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
@@ -662,12 +687,17 @@ static int prepare_fused(mgs_hier *h) {
     if (L.A->cols > L.A->rows && !L.hbuf) MGS_TRY(mgs_vec_create(ctx, L.A->cols - L.A->rows, &L.hbuf));
     const bool rescale = L.wd_omega != h->omega;
     if (rescale) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
-    if (ctx->opt_fuse_operands && L.A->rows == L.A->cols) {      // derived CSR operands of the fused passes (same shape as A)
+    if (ctx->opt_fuse_operands) {      // derived CSR operands of the fused passes (same shape as A)
+      const bool shard = L.A->cols > L.A->rows;
       if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); }
       else if (rescale) MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd));
       if (!L.col_agg) {
-        MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.col_agg)); drop_graph(h);
-        if (ctx->opt_rowcode) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, &L.code_agg));
+        MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.T->n_coarse, L.col_agg)); drop_graph(h);
+        if (ctx->opt_rowcode) {
+          MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg));
+          // on a shard the pre pass reads b (owned entries only) + the payload: halo columns need tagged table words
+          if (shard) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, L.A->rows, &L.code_pre));
+        }
       }
     }
   }

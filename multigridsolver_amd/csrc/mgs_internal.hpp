@@ -101,6 +101,7 @@ struct mgs_level {
   double *val_wd = nullptr;    // setup-time operand of the fused pre pass: a_ij·wd_j, so A·(wd∘b) = Â·b needs one gather
   int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
+  mgs_rowcode *code_pre = nullptr;   // row shards: pattern code of col with tagged halo words (pre pass reads b + payload)
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -168,12 +169,15 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
                             const double *dinv, double omega, double *out, int blk_lo, int blk_hi);
 int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
                            const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi);
-int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);
-int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int *out);
+int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);            // halo columns (>= rows) keep their value
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int *out);        // halo column c -> n_coarse + (c − rows)
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
 int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);
-int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, mgs_rowcode **out);
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out);
+bool mgs_rowcode_usable(const mgs_csr *A);
+int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
+                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi);
 void mgs_free_rowcode(mgs_rowcode *c);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
