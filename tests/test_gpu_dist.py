@@ -52,3 +52,10 @@ def test_solve_cli_single_and_sharded(inputs, orc, tmp_path):
         assert r.returncode == 0 and "Number of iterations BICG" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         x = np.fromfile(dump, dtype="<f8")
         assert np.linalg.norm(Ao.residual(x, b)) / np.linalg.norm(b) < 1.5e-9
+
+
+def test_rccl_transport_on_library_memory_world1():
+    """the RCCL transport itself (backend nccl) at world 1: collectives on library-owned device memory, blocking and async"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "nccl_world1_worker.py")], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0 and "NCCL_W1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
