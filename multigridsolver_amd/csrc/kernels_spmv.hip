@@ -54,7 +54,9 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // 7-point stencil): instead of plane after plane, a strip of S row blocks is followed through all
 // planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
 // p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
-struct BlockMap { int nblocks, chunk, remap, D, S, P, base; };   // base: first row block of the launched range
+struct BlockMap { int nblocks, chunk, remap, D, S, P, base, gap_at = 0x7fffffff, gap_len = 0; };   // base: first row block of the launched range;
+// row blocks >= gap_at are shifted by gap_len (one launch over the leading + trailing boundary blocks of a row shard)
+__device__ __forceinline__ int block_of(const BlockMap &m, int vb) { const int b = m.base + vb; return b >= m.gap_at ? b + m.gap_len : b; }
 __device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx);
 __device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
   if (!m.remap) return bid < m.nblocks ? bid : -1;
@@ -168,13 +170,14 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
-  const int r0 = (bm.base + vb) * RB;
+  const int blk = block_of(bm, vb);
+  const int r0 = blk * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
   // block bounds from the compact per-block copy of rowptr (consecutive workgroups share cache lines;
   // rowptr[r0] itself is 1 KiB apart from block to block)
-  const int lo = blkptr ? blkptr[bm.base + vb] : rowptr[r0];
-  const int hi = blkptr ? blkptr[bm.base + vb + 1] : rowptr[r1];
+  const int lo = blkptr ? blkptr[blk] : rowptr[r0];
+  const int hi = blkptr ? blkptr[blk + 1] : rowptr[r1];
   if (hi - lo <= cap) {
     double *__restrict__ vals = lds_raw;                                   // cap + 2 doubles
     int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);   // cap + 2 ints
@@ -290,11 +293,12 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
-  const int r0 = (bm.base + vb) * RB;
+  const int blk = block_of(bm, vb);
+  const int r0 = blk * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
-  const int lo = blkptr ? blkptr[bm.base + vb] : rowptr[r0];
-  const int hi = blkptr ? blkptr[bm.base + vb + 1] : rowptr[r1];
+  const int lo = blkptr ? blkptr[blk] : rowptr[r0];
+  const int hi = blkptr ? blkptr[blk + 1] : rowptr[r1];
   double *__restrict__ vals = lds_raw;
   int *__restrict__ cols = reinterpret_cast<int *>(lds_raw + cap + 2);
   const int row = r0 + tid;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
-  const int blk = bm.base + vb;
+  const int blk = block_of(bm, vb);
   const int r0 = blk * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
@@ -923,11 +927,13 @@ static dim3 plan_block_map(const mgs_csr *A, int blk_lo, int blk_hi, BlockMap &b
 // The coded kernel on the row blocks [blk_lo, blk_hi) of the view A (A->col = the coded index array, A->code its
 // code); hv/split: halo payload of a row shard (nullptr / INT_MAX: none).  Caller checks mgs_rowcode_usable(A).
 int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
-                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi) {
+                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,
+                           int gap_at, int gap_len) {
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
   if (!use_rowcode(A, A->code)) return MGS_ERR_STATE;
   BlockMap bm;
   const dim3 grid = plan_block_map(A, blk_lo, blk_hi, bm);
+  bm.gap_at = gap_at; bm.gap_len = gap_len;
   return launch_coded(A, A->code, op, A->col, x, b, dinv, omega, xin, agg, out, grid, bm, hv, hv ? split : 0x7fffffff);
 }
 
@@ -943,11 +949,12 @@ int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double
 }
 // row blocks [blk_lo, blk_hi); hv = values of the halo columns (nullptr for a square operator)
 int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
-                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi) {
+                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi, int gap_at, int gap_len) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
   if (A->lds_cap <= 0 || (A->rows != A->cols && !hv)) return MGS_ERR_STATE;
   BlockMap bm;
+  bm.gap_at = gap_at; bm.gap_len = gap_len;
   bm.base = blk_lo; bm.nblocks = blk_hi - blk_lo;
   bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
   bm.chunk = (bm.nblocks + 7) / 8;
@@ -974,10 +981,15 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
 
 // the same kernels on the row blocks [blk_lo, blk_hi) only (interior / boundary split of a row shard)
 int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv,
-                            double omega, double *out, int blk_lo, int blk_hi) {
+                            double omega, double *out, int blk_lo, int blk_hi, int gap_at, int gap_len) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
+  if (gap_len > 0 && ctx->opt_spmv_variant != 0 && ctx->opt_spmv_variant != 5) {   // experimental variants: no gap support
+    MGS_TRY(mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, blk_lo, gap_at, 0x7fffffff, 0));
+    return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, gap_at + gap_len, blk_hi + gap_len, 0x7fffffff, 0);
+  }
   BlockMap bm;
+  bm.gap_at = gap_at; bm.gap_len = gap_len;
   bm.base = blk_lo;
   bm.nblocks = blk_hi - blk_lo;
   bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;

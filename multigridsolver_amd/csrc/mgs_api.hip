@@ -65,6 +65,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
   else if (k == "fuse_operands") ctx->opt_fuse_operands = value;
   else if (k == "rowcode") ctx->opt_rowcode = value;
+  else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
@@ -499,6 +500,9 @@ int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
 // bit-identical shortcuts that skip one SpMV-sized pass each.
 int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const double *b, double *x);
 
+// Below opt_split_min_rows owned rows a level's kernel is too short to hide an exchange behind its interior row blocks:
+// exchange first, then one launch (one launch less per pass).
+
 static int halo_x(mgs_hier *h, int l, double *x) {
   if (!h->halo) return MGS_OK;
   int rc = h->halo(h->halo_user, l, x);
@@ -508,15 +512,14 @@ static int halo_x(mgs_hier *h, int l, double *x) {
 // interior row blocks run while the exchange is in flight
 static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out) {
   if (!h->halo && !h->halo_begin) return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
-  if (h->halo_begin && A->halo_split_ok) {
+  if (h->halo_begin && A->halo_split_ok && A->rows >= h->ctx->opt_split_min_rows) {
     const int nb = (A->rows + 255) / 256, lo = A->halo_lo_blocks, hi = nb - A->halo_hi_blocks;
     int rc = h->halo_begin(h->halo_user, l, x);
     if (rc) return mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange (begin) failed at level %d (%d)", l, rc);
     MGS_TRY(mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, lo, hi));
     rc = h->halo_end(h->halo_user, l, x);
     if (rc) return mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange (end) failed at level %d (%d)", l, rc);
-    MGS_TRY(mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, lo));
-    return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, hi, nb);
+    return mgs_launch_csr_op_range(A, op, x, b, dinv, omega, out, 0, lo + nb - hi, lo, hi - lo);   // leading + trailing boundary blocks, one launch
   }
   if (h->halo) MGS_TRY(halo_x(h, l, x));
   else {   // split callbacks only, but this level's halo readers are scattered: exchange, then one launch
@@ -588,18 +591,18 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     const double *hv = halo ? L.hbuf->d : nullptr;
     const int nb = (L.A->rows + 255) / 256;
     // interior row blocks run while the payload of the halo columns is in flight
-    const int lo = (halo && L.A->halo_split_ok) ? L.A->halo_lo_blocks : 0, hi = (halo && L.A->halo_split_ok) ? nb - L.A->halo_hi_blocks : nb;
+    const bool split = halo && L.A->halo_split_ok && L.A->rows >= h->ctx->opt_split_min_rows;
+    const int lo = split ? L.A->halo_lo_blocks : 0, hi = split ? nb - L.A->halo_hi_blocks : nb;
     auto fused_pass = [&](int which, int kind, const void *pa, const void *pb, const double *bvec, const double *xin, const int *agg,
                           const double *ec, double *out, double *out2) -> int {
       if (!halo) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, nullptr, 0, nb);
       int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
-      if (L.A->halo_split_ok) MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, lo, hi));
+      if (split) MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, lo, hi));
       rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 1);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (end) failed at level %d (%d)", l, rc);
-      if (!L.A->halo_split_ok) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, nb);
-      MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo));
-      return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, hi, nb);
+      if (!split) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, nb);
+      return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo + nb - hi, lo, hi - lo);
     };
     // Setup-time operands: Â = A·diag(wd) makes the pre pass the plain residual kernel with x = b (one gather per
     // entry), col_agg = agg[col] lets the post pass gather e_c directly.  On a shard the halo columns read the
@@ -609,15 +612,14 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
                           (!halo || (mgs_rowcode_usable(&Ahat) && mgs_rowcode_usable(&Amap)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
-                          const double *dv, const double *xin, const int *agg, double *out, int split) -> int {
+                          const double *dv, const double *xin, const int *agg, double *out, int isplit) -> int {
       int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
-      if (L.A->halo_split_ok) MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, lo, hi));
+      if (split) MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, lo, hi));
       rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 1);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (end) failed at level %d (%d)", l, rc);
-      if (!L.A->halo_split_ok) return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, 0, nb);
-      MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, 0, lo));
-      return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, split, hi, nb);
+      if (!split) return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, nb);
+      return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, lo + nb - hi, lo, hi - lo);
     };
     // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
     if (operands && halo) MGS_TRY(coded_pass(&Ahat, MGS_OP_RESIDUAL, 0, L.wd->d, b, b, b, nullptr, nullptr, nullptr, L.r->d, L.A->rows));

@@ -29,6 +29,7 @@ struct mgs_ctx {
   int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_split_min_rows = 400000;   // row shards: levels with fewer owned rows exchange first and launch once (no interior/boundary split)
   int opt_rowcode = 1;   // pattern-coded index (8 B per entry streamed instead of 12 where rows repeat their shape)
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
@@ -165,10 +166,13 @@ int mgs_launch_fused(const mgs_csr *A, int which, const double *wd, const double
                      const double *ec, double *out, double *out2);
 int mgs_launch_csr_op(const mgs_csr *A, int op, const double *x, const double *b,
                       const double *dinv, double omega, double *out);
+// row blocks [blk_lo, blk_hi) of a virtual numbering in which the blocks >= gap_at are shifted by gap_len (one launch over
+// the leading and trailing boundary blocks of a row shard: range [0, lo + nb − hi), gap_at = lo, gap_len = hi − lo)
 int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const double *b,
-                            const double *dinv, double omega, double *out, int blk_lo, int blk_hi);
+                            const double *dinv, double omega, double *out, int blk_lo, int blk_hi, int gap_at = 0x7fffffff, int gap_len = 0);
 int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
-                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi);
+                           const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi,
+                           int gap_at = 0x7fffffff, int gap_len = 0);
 int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);            // halo columns (>= rows) keep their value
 int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int *out);        // halo column c -> n_coarse + (c − rows)
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
@@ -177,7 +181,8 @@ int mgs_plan_csr(mgs_csr *A);
 int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out);
 bool mgs_rowcode_usable(const mgs_csr *A);
 int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
-                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi);
+                           const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,
+                           int gap_at = 0x7fffffff, int gap_len = 0);
 void mgs_free_rowcode(mgs_rowcode *c);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);

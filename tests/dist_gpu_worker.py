@@ -45,6 +45,7 @@ def main():
     n_loc, n_ext = A.shape
     sh = mgd.ShardedHierarchy(ctx, A, plan0, 0.6, 1, 1, comm)
     sh.overlap_min_rows = 0   # exercise the asynchronous form on every level
+    ctx.set_option("split_min_rows", 0 if N != 24 else 400000)   # ... and the interior/boundary split (N = 24: the exchange-then-one-launch form)
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap, fused=fused)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     if not mtx:
