@@ -272,6 +272,28 @@ int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double 
  * row-block kernel, [4]=leading and [5]=trailing row blocks that read halo columns, [6]=1 if the
  * interior/boundary split is usable, [7]=1 if some block takes the long-row path.            */
 int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
+/* ---- native RCCL transport of a row-sharded hierarchy (no reference counterpart: the reference is single-process) ----
+ * One communicator per process/GPU.  librccl is resolved at run time from `librccl_path` — pass the copy the launcher
+ * already loaded (for torch.distributed: <torch>/lib/librccl.so) so the process holds a single RCCL instance.  Rank 0
+ * calls mgs_comm_unique_id and ships the MGS_COMM_ID_BYTES bytes to the other ranks by any means; every rank then
+ * calls mgs_comm_create.  All communication is enqueued on the context's stream.
+ *   mgs_hier_set_native_exchange: halo plan of `level` — send_idx (host): owned rows the peers need, peer after peer;
+ *     send_counts/recv_counts: per peer; the received values fill the level's halo slots in peer order.  With a plan
+ *     installed the cycle packs and exchanges by itself (ncclSend/ncclRecv group) and ignores the exchange callbacks
+ *     for that level.  comm = NULL removes the plan.
+ *   mgs_hier_set_native_tail: the coarsest sharded level is all-gathered (ncclAllGather) and solved by `tail`, an
+ *     unsharded hierarchy on the globally assembled operator replicated on every rank; nlocs = rows per rank.
+ *   mgs_hier_native_halo: one plain halo exchange of the level-`level` vector x_dev (owned entries + halo room).  */
+#define MGS_COMM_ID_BYTES 128
+typedef struct mgs_comm mgs_comm;
+int mgs_comm_unique_id(mgs_ctx *ctx, const char *librccl_path, void *id_out);
+int mgs_comm_create(mgs_ctx *ctx, const char *librccl_path, const void *id, int world, int rank, mgs_comm **out);
+int mgs_comm_destroy(mgs_comm *c);
+int mgs_comm_size(const mgs_comm *c, int *world, int *rank);
+int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int *send_idx, const int *send_counts, const int *recv_counts);
+int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs);
+int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev);
+
 /* Builds the pattern code of A's column array (one byte per row + a small table per 256-row block) so the
  * SpMV-shaped kernels stream 8 instead of 12 bytes per entry wherever rows repeat their shape (stencil-like
  * operators); results stay bit-identical.  Hierarchies and the Krylov solvers call it for their operators; call

@@ -35,6 +35,13 @@ PROTOTYPES = {
     "mgs_csr_download": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_dbl_p]),
     "mgs_csr_shape": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_i64_p]),
     "mgs_csr_plan_info": (C.c_int, [C.c_void_p, c_i64_p]),
+    "mgs_comm_unique_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "mgs_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mgs_comm_destroy": (C.c_int, [C.c_void_p]),
+    "mgs_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mgs_hier_set_native_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_hier_set_native_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_hier_native_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgs_csr_optimize": (C.c_int, [C.c_void_p]),
     "mgs_hier_fused_info": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "mgs_csr_rowcode_info": (C.c_int, [C.c_void_p, c_i64_p]),

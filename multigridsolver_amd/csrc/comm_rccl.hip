@@ -1,0 +1,114 @@
+// comm_rccl.hip — native RCCL transport of the row-sharded cycle (one process per GPU, xGMI point-to-point).
+//
+// The exchange step of the path is a neighbour exchange of halo values: a pack kernel, then one
+// RCCL group of ncclSend/ncclRecv to the peers that own halo columns — enqueued by the C++ cycle itself on the
+// context's stream, so a sharded cycle needs no host callback and no cross-stream dependency per exchange.  The
+// replicated coarse tail gathers its right-hand side with one ncclAllGather.
+//
+// librccl is NOT a link dependency: the process has already loaded the copy its launcher (torch.distributed) uses;
+// the entry points are resolved from that same file with dlopen/dlsym (path handed in by the host side), so there is
+// exactly one RCCL instance per process.  <rccl/rccl.h> supplies types and enums only.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "mgs_internal.hpp"
+
+struct mgs_comm {
+  mgs_ctx *ctx = nullptr;
+  void *dl = nullptr;
+  ncclComm_t comm = nullptr;
+  int world = 0, rank = 0;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+#define MGS_NCCL(c, call)                                                                                  \
+  do {                                                                                                     \
+    ncclResult_t r_ = (call);                                                                              \
+    if (r_ != ncclSuccess)                                                                                 \
+      return mgs_fail((c)->ctx, MGS_ERR_STATE, "%s failed: %s", #call, (c)->GetErrorString ? (c)->GetErrorString(r_) : "?"); \
+  } while (0)
+
+static int load_api(mgs_ctx *ctx, const char *librccl, mgs_comm *c) {
+  c->ctx = ctx;
+  c->dl = dlopen(librccl, RTLD_NOW | RTLD_GLOBAL);
+  if (!c->dl) return mgs_fail(ctx, MGS_ERR_STATE, "dlopen(%s): %s", librccl ? librccl : "(null)", dlerror());
+#define SYM(field, name)                                                               \
+  c->field = reinterpret_cast<decltype(c->field)>(dlsym(c->dl, name));                 \
+  if (!c->field) return mgs_fail(ctx, MGS_ERR_STATE, "%s: symbol %s missing", librccl, name)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+  SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  return MGS_OK;
+}
+
+extern "C" {
+
+int mgs_comm_unique_id(mgs_ctx *ctx, const char *librccl, void *id_out) {
+  MGS_CHECK(ctx, id_out, MGS_ERR_INVALID, "mgs_comm_unique_id: NULL output");
+  mgs_comm tmp;
+  MGS_TRY(load_api(ctx, librccl, &tmp));
+  ncclUniqueId id;
+  MGS_NCCL(&tmp, tmp.GetUniqueId(&id));
+  static_assert(sizeof(id) == MGS_COMM_ID_BYTES, "RCCL unique id size");
+  memcpy(id_out, &id, sizeof id);
+  return MGS_OK;
+}
+
+int mgs_comm_create(mgs_ctx *ctx, const char *librccl, const void *id_in, int world, int rank, mgs_comm **out) {
+  MGS_CHECK(ctx, out && id_in && world >= 1 && rank >= 0 && rank < world, MGS_ERR_INVALID, "mgs_comm_create: bad arguments");
+  mgs_comm *c = new mgs_comm();
+  int rc = load_api(ctx, librccl, c);
+  if (rc != MGS_OK) { delete c; return rc; }
+  c->world = world; c->rank = rank;
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof id);
+  hipSetDevice(ctx->device);
+  ncclResult_t r = c->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { rc = mgs_fail(ctx, MGS_ERR_STATE, "ncclCommInitRank(world %d, rank %d): %s", world, rank, c->GetErrorString(r)); delete c; return rc; }
+  *out = c;
+  return MGS_OK;
+}
+
+int mgs_comm_destroy(mgs_comm *c) {
+  if (!c) return MGS_OK;
+  if (c->comm && c->CommDestroy) c->CommDestroy(c->comm);
+  delete c;      // the library handle stays open: the process keeps using it
+  return MGS_OK;
+}
+
+int mgs_comm_size(const mgs_comm *c, int *world, int *rank) { if (world) *world = c->world; if (rank) *rank = c->rank; return MGS_OK; }
+
+}  // extern "C"
+
+// neighbour exchange on the context's stream: peer p gets scnt[p] doubles from send (packed peer after peer) and
+// delivers rcnt[p] doubles into recv (peer after peer); zero counts issue nothing
+int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *recv, const int *rcnt) {
+  hipStream_t s = c->ctx->stream;
+  MGS_NCCL(c, c->GroupStart());
+  size_t so = 0, ro = 0;
+  for (int p = 0; p < c->world; ++p) {
+    if (scnt[p]) MGS_NCCL(c, c->Send(send + so, (size_t)scnt[p], ncclDouble, p, c->comm, s));
+    if (rcnt[p]) MGS_NCCL(c, c->Recv(recv + ro, (size_t)rcnt[p], ncclDouble, p, c->comm, s));
+    so += (size_t)scnt[p]; ro += (size_t)rcnt[p];
+  }
+  MGS_NCCL(c, c->GroupEnd());
+  return MGS_OK;
+}
+int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count) {
+  MGS_NCCL(c, c->AllGather(send, recv, count, ncclDouble, c->comm, c->ctx->stream));
+  return MGS_OK;
+}
+int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count) {
+  MGS_NCCL(c, c->AllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->ctx->stream));
+  return MGS_OK;
+}

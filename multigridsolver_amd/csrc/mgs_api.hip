@@ -15,6 +15,20 @@ int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...) {
   return code;
 }
 
+// halo values for level l through the native transport, on the context's stream.
+// kind 0: wd∘b of the rows the peers see as halo (pa = wd, pb = b); 1: e_c[agg] (pa = e_c, pb = agg); 2: x itself (pa = x)
+static int native_exchange(mgs_hier *h, int l, int kind, const void *pa, const void *pb, double *out) {
+  mgs_native_plan *P = h->lev[l].nx;
+  mgs_ctx *ctx = h->ctx;
+  if (P->ns) {
+    if (kind == 0) MGS_TRY(k_gather_prod(ctx, (const double *)pa, (const double *)pb, P->send_idx, P->ns, P->sendbuf));
+    else if (kind == 1) MGS_TRY(k_gather_pe(ctx, (const double *)pa, (const int *)pb, P->send_idx, P->ns, P->sendbuf));
+    else MGS_TRY(k_gather(ctx, (const double *)pa, P->send_idx, P->ns, P->sendbuf));
+  }
+  if (P->ns || P->nr) MGS_TRY(mgs_comm_exchange(P->comm, P->sendbuf, P->scnt.data(), out, P->rcnt.data()));
+  return MGS_OK;
+}
+
 extern "C" {
 
 const char *mgs_version(void) { return "multigridsolver_amd 0.1 (gfx950, f64)"; }
@@ -308,6 +322,7 @@ static void level_free(mgs_level &L) {
   if (L.col_agg) hipFree(L.col_agg);
   mgs_free_rowcode(L.code_agg);
   mgs_free_rowcode(L.code_pre);
+  if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
   L = mgs_level();
@@ -330,12 +345,20 @@ int mgs_hier_create(mgs_ctx *ctx, const mgs_csr *A, double omega, int nu1, int n
   *out = h;
   return MGS_OK;
 }
+static void free_native_tail(mgs_hier *h) {
+  mgs_native_tail *T = h->ntail;
+  if (!T) return;
+  if (T->send) hipFree(T->send); if (T->all) hipFree(T->all); if (T->gidx) hipFree(T->gidx);
+  mgs_vec_destroy(T->b); mgs_vec_destroy(T->x);
+  delete T; h->ntail = nullptr;
+}
 int mgs_hier_destroy(mgs_hier *h) {
   if (!h) return MGS_OK;
   hipStreamSynchronize(h->ctx->stream);
   drop_graph(h);
   for (auto &L : h->lev) level_free(L);
   if (h->inv) hipFree(h->inv);
+  free_native_tail(h);
   delete h;
   return MGS_OK;
 }
@@ -343,6 +366,53 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2) {
   MGS_CHECK(h->ctx, nu1 >= 0 && nu2 >= 0, MGS_ERR_INVALID, "negative sweep count");
   h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; drop_graph(h);
   return MGS_OK;
+}
+// ---- native RCCL transport of a sharded hierarchy (comm_rccl.hip) ----
+int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int *send_idx, const int *send_counts, const int *recv_counts) {
+  mgs_ctx *ctx = h->ctx;
+  MGS_CHECK(ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d out of range", level);
+  mgs_level &L = h->lev[level];
+  if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
+  drop_graph(h);
+  if (!c) { h->native = false; for (auto &q : h->lev) h->native = h->native || q.nx; return MGS_OK; }
+  int world = 0; mgs_comm_size(c, &world, nullptr);
+  mgs_native_plan *P = new mgs_native_plan();
+  P->comm = c; P->scnt.assign(send_counts, send_counts + world); P->rcnt.assign(recv_counts, recv_counts + world);
+  for (int p = 0; p < world; ++p) { P->ns += P->scnt[p]; P->nr += P->rcnt[p]; }
+  L.nx = P;
+  MGS_CHECK(ctx, P->nr == (int64_t)L.A->cols - L.A->rows, MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d has %d halo columns, plan delivers %lld",
+            level, L.A->cols - L.A->rows, (long long)P->nr);
+  MGS_TRY(mgs_dev_alloc(ctx, &P->send_idx, (size_t)P->ns));
+  MGS_TRY(mgs_dev_alloc(ctx, &P->sendbuf, (size_t)P->ns));
+  if (P->ns) MGS_HIP(ctx, hipMemcpy(P->send_idx, send_idx, sizeof(int) * (size_t)P->ns, hipMemcpyHostToDevice));
+  h->native = true;
+  return MGS_OK;
+}
+int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs) {
+  mgs_ctx *ctx = h->ctx;
+  free_native_tail(h);
+  drop_graph(h);
+  if (!c || !tail) return MGS_OK;
+  int world = 0, rank = 0; mgs_comm_size(c, &world, &rank);
+  mgs_native_tail *T = new mgs_native_tail();
+  h->ntail = T;
+  T->comm = c; T->tail = tail; T->n_loc = nlocs[rank];
+  std::vector<int> gi;
+  for (int p = 0; p < world; ++p) { T->maxn = std::max(T->maxn, nlocs[p]); }
+  for (int p = 0; p < world; ++p) { if (p == rank) T->my_off = (int)gi.size(); for (int j = 0; j < nlocs[p]; ++j) gi.push_back(p * T->maxn + j); }
+  T->n_t = (int)gi.size();
+  MGS_CHECK(ctx, T->n_t == tail->lev[0].n && T->n_loc == h->lev.back().n, MGS_ERR_INVALID, "mgs_hier_set_native_tail: tail has %d rows, shards sum to %d", tail->lev[0].n, T->n_t);
+  MGS_TRY(mgs_dev_alloc(ctx, &T->send, (size_t)std::max(T->maxn, 1)));
+  MGS_TRY(mgs_dev_alloc(ctx, &T->all, (size_t)std::max(T->maxn, 1) * world));
+  MGS_TRY(mgs_dev_alloc(ctx, &T->gidx, (size_t)T->n_t));
+  MGS_HIP(ctx, hipMemset(T->send, 0, sizeof(double) * (size_t)std::max(T->maxn, 1)));
+  MGS_HIP(ctx, hipMemcpy(T->gidx, gi.data(), sizeof(int) * gi.size(), hipMemcpyHostToDevice));
+  MGS_TRY(mgs_vec_create(ctx, T->n_t, &T->b)); MGS_TRY(mgs_vec_create(ctx, T->n_t, &T->x));
+  return MGS_OK;
+}
+int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev) {
+  MGS_CHECK(h->ctx, level >= 0 && level < (int)h->lev.size() && h->lev[level].nx, MGS_ERR_STATE, "mgs_hier_native_halo: level %d has no native plan", level);
+  return native_exchange(h, level, 2, x_dev, nullptr, (double *)x_dev + h->lev[level].A->rows);
 }
 int mgs_hier_set_halo_exchange_fused(mgs_hier *h, mgs_halo_fused_fn fn, void *user) { h->halo_fused = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
 int mgs_halo_pack_prod(mgs_ctx *ctx, const void *wd, const void *b, const int *idx, int64_t n, double *buf) { return k_gather_prod(ctx, (const double *)wd, (const double *)b, idx, n, buf); }
@@ -504,6 +574,7 @@ int k_jacobi_zero(mgs_ctx *ctx, int n, double omega, const double *dinv, const d
 // exchange first, then one launch (one launch less per pass).
 
 static int halo_x(mgs_hier *h, int l, double *x) {
+  if (h->lev[l].nx) return native_exchange(h, l, 2, x, nullptr, x + h->lev[l].A->rows);
   if (!h->halo) return MGS_OK;
   int rc = h->halo(h->halo_user, l, x);
   return rc ? mgs_fail(h->ctx, MGS_ERR_STATE, "halo exchange callback failed at level %d (%d)", l, rc) : MGS_OK;
@@ -511,6 +582,10 @@ static int halo_x(mgs_hier *h, int l, double *x) {
 // one SpMV-shaped kernel on level l with x's halo refreshed first; with split-phase callbacks the
 // interior row blocks run while the exchange is in flight
 static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out) {
+  if (h->lev[l].nx) {    // native RCCL exchange on this stream, then one launch
+    MGS_TRY(native_exchange(h, l, 2, x, nullptr, x + A->rows));
+    return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
+  }
   if (!h->halo && !h->halo_begin) return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
   if (h->halo_begin && A->halo_split_ok && A->rows >= h->ctx->opt_split_min_rows) {
     const int nb = (A->rows + 255) / 256, lo = A->halo_lo_blocks, hi = nb - A->halo_hi_blocks;
@@ -538,7 +613,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 //   c1 = B rhs, v1 = A c1, r' = rhs − (α1/ρ1) v1;  c2 = B r', v2 = A c2;
 //   x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1.
 static bool kcycle_here(const mgs_hier *h, int l) {
-  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && !h->halo && !h->halo_begin && h->lev[l].kscal;
+  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && !h->halo && !h->halo_begin && !h->native && h->lev[l].kscal;
 }
 static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
   if (!kcycle_here(h, l)) return cycle_level(h, l, rhs, x, true);
@@ -564,6 +639,15 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   mgs_level &L = h->lev[l];
   const int n = L.n;
   if (l == (int)h->lev.size() - 1) {
+    if (h->ntail) {                                     // replicated tail, native: all-gather the rhs, cycle, own slice back
+      mgs_native_tail *T = h->ntail;
+      if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(T->send, b, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
+      MGS_TRY(mgs_comm_allgather(T->comm, T->send, T->all, (size_t)std::max(T->maxn, 1)));
+      MGS_TRY(k_gather(ctx, T->all, T->gidx, T->n_t, T->b->d));
+      MGS_TRY(mgs_vcycle(T->tail, T->b, T->x, 1));
+      if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(x, T->x->d + T->my_off, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
+      return MGS_OK;
+    }
     if (h->coarse) { int rc = h->coarse(h->coarse_user, b, x); return rc ? mgs_fail(ctx, MGS_ERR_STATE, "coarse solver callback failed (%d)", rc) : MGS_OK; }
     if (h->coarse_sweeps > 0) {                        // smoothed coarsest level (see mgs_hier_finalize)
       double *cur = x, *alt = L.tmp->d;
@@ -582,10 +666,10 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   mgs_level &C = h->lev[l + 1];
   // ---- fused form (square unsharded level, aggregation P, V(1,1) from x = 0): two matrix passes,
   //      no separate (ωD⁻¹)b / prolong-add kernels
-  const bool sharded = h->halo || h->halo_begin;
+  const bool sharded = h->halo || h->halo_begin || h->native;
   const bool can_fuse = ctx->opt_fuse && zero_guess && h->nu1 == 1 && h->nu2 == 1 && L.wd && L.wd_omega == h->omega &&
                         L.T->aggregation && L.A->lds_cap > 0 &&
-                        (sharded ? (h->halo_fused != nullptr && (L.A->rows == L.A->cols || L.hbuf)) : L.A->rows == L.A->cols);
+                        (sharded ? ((h->halo_fused != nullptr || L.nx) && (L.A->rows == L.A->cols || L.hbuf)) : L.A->rows == L.A->cols);
   if (can_fuse) {
     const bool halo = L.A->cols > L.A->rows;
     const double *hv = halo ? L.hbuf->d : nullptr;
@@ -596,6 +680,10 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     auto fused_pass = [&](int which, int kind, const void *pa, const void *pb, const double *bvec, const double *xin, const int *agg,
                           const double *ec, double *out, double *out2) -> int {
       if (!halo) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, nullptr, 0, nb);
+      if (L.nx) {
+        MGS_TRY(native_exchange(h, l, kind, pa, pb, L.hbuf->d));
+        return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, nb);
+      }
       int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
       if (split) MGS_TRY(mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, lo, hi));
@@ -613,6 +701,10 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
                           (!halo || (mgs_rowcode_usable(&Ahat) && mgs_rowcode_usable(&Amap)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
                           const double *dv, const double *xin, const int *agg, double *out, int isplit) -> int {
+      if (L.nx) {      // native RCCL exchange of the payload on this stream, then one launch
+        MGS_TRY(native_exchange(h, l, kind, pa, pb, L.hbuf->d));
+        return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, nb);
+      }
       int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
       if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange (begin) failed at level %d (%d)", l, rc);
       if (split) MGS_TRY(mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, lo, hi));
@@ -679,12 +771,12 @@ static int prepare_fused(mgs_hier *h) {
     MGS_TRY(mgs_dev_alloc(ctx, &L.kscal, 8));
     drop_graph(h);
   }
-  const bool sharded = h->halo || h->halo_begin;
-  if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || (sharded && !h->halo_fused)) return MGS_OK;
+  const bool sharded = h->halo || h->halo_begin || h->native;
+  if (!ctx->opt_fuse || h->nu1 != 1 || h->nu2 != 1 || (sharded && !h->halo_fused && !h->native)) return MGS_OK;
   for (size_t l = 0; l + 1 < h->lev.size(); ++l) {
     mgs_level &L = h->lev[l];
     if (!L.T || !L.T->aggregation) continue;
-    if (L.A->rows != L.A->cols && !h->halo_fused) continue;
+    if (L.A->rows != L.A->cols && !h->halo_fused && !L.nx) continue;
     if (!L.wd) MGS_TRY(mgs_vec_create(ctx, L.n, &L.wd));
     if (L.A->cols > L.A->rows && !L.hbuf) MGS_TRY(mgs_vec_create(ctx, L.A->cols - L.A->rows, &L.hbuf));
     const bool rescale = L.wd_omega != h->omega;
@@ -720,7 +812,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
-  const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse;
+  const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse && !h->native && !h->ntail;
   const int gkey = ctx->opt_fuse * 4 + ctx->opt_fuse_operands * 2 + ctx->opt_rowcode;
   if (h->graph_fuse != gkey) drop_graph(h);
   h->graph_fuse = gkey;
@@ -772,6 +864,7 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
   if (x->n < next) { MGS_TRY(mgs_vec_create(ctx, next, &xe)); guard.vs.push_back(&xe); MGS_TRY(mgs_vec_copy(&xv, xe)); xin = xe; }
   auto halo0 = [&](mgs_vec *w) -> int {
     if (!h) return 0;
+    if (h->lev[0].nx) return native_exchange(h, 0, 2, w->d, nullptr, w->d + A->rows);
     if (h->halo) return h->halo(h->halo_user, 0, w->d);
     if (h->halo_begin) { int rc = h->halo_begin(h->halo_user, 0, w->d); return rc ? rc : h->halo_end(h->halo_user, 0, w->d); }
     return 0;

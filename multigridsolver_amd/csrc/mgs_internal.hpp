@@ -90,6 +90,30 @@ struct mgs_xfer {
   mgs_csr *P = nullptr, *Pt = nullptr;
 };
 
+// native RCCL transport (comm_rccl.hip)
+struct mgs_comm;
+int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *recv, const int *rcnt);
+int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count);
+int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count);
+// halo plan of one sharded level for the native exchange
+struct mgs_native_plan {
+  mgs_comm *comm = nullptr;
+  int *send_idx = nullptr;          // device: owned rows the peers need, peer after peer
+  std::vector<int> scnt, rcnt;      // per peer
+  int64_t ns = 0, nr = 0;
+  double *sendbuf = nullptr;        // device, ns doubles
+};
+struct mgs_hier;
+// replicated coarse tail driven natively: all-gather of the right-hand side, tail cycle, own slice back
+struct mgs_native_tail {
+  mgs_comm *comm = nullptr;
+  mgs_hier *tail = nullptr;         // not owned
+  int maxn = 0, n_t = 0, my_off = 0, n_loc = 0;
+  double *send = nullptr, *all = nullptr;   // maxn / world·maxn doubles
+  int *gidx = nullptr;              // n_t: position of global tail row i in `all`
+  mgs_vec *b = nullptr, *x = nullptr;
+};
+
 struct mgs_level {
   const mgs_csr *A = nullptr;
   bool own_A = false;
@@ -107,6 +131,7 @@ struct mgs_level {
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
   mgs_vec *b = nullptr, *x = nullptr;  // coarse-level rhs / solution (levels >= 1)
+  mgs_native_plan *nx = nullptr;       // native RCCL halo exchange of this level (row shards)
 };
 
 struct mgs_hier {
@@ -124,6 +149,8 @@ struct mgs_hier {
   void *halo_user = nullptr;
   mgs_halo_fn halo_begin = nullptr, halo_end = nullptr;   // split-phase exchange (overlap with interior rows)
   mgs_halo_fused_fn halo_fused = nullptr;                  // payload exchange of the fused passes on row shards
+  mgs_native_tail *ntail = nullptr;  // native form of the replicated tail (takes precedence over `coarse`)
+  bool native = false;               // some level exchanges natively: sharded semantics even without callbacks
   mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
   void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle

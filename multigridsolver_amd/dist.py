@@ -189,7 +189,7 @@ class Comm:
         """in-place reduction of a float64 numpy array over ranks"""
         t, d = self.torch, self.dist
         x = t.from_numpy(a).to(self.cdev)
-        d.all_reduce(x, op=d.ReduceOp.SUM if op == "sum" else d.ReduceOp.MAX)
+        d.all_reduce(x, op={"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN}[op])
         a[:] = x.cpu().numpy()
 
     def a2a_f64(self, recv, send, recv_counts, send_counts, async_op=False):
@@ -308,7 +308,7 @@ class ShardedHierarchy:
         self._pending[("f", level)] = self.comm.a2a_f64(recv, buf[:ns], plan.recv_counts, plan.send_counts, async_op=big)
 
     # ---- setup
-    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=2500, max_levels=32, log=None, overlap=True, fused=True):
+    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=2500, max_levels=32, log=None, overlap=True, fused=True, native=None):
         comm, ctx = self.comm, self.ctx
         self._prepare_plan(0)
         A = self.A
@@ -343,7 +343,66 @@ class ShardedHierarchy:
             self.h.set_halo_exchange(self._exchange)
         if fused:
             self.h.set_halo_exchange_fused(self._exchange_fused)
+        if native is None:
+            native = comm.nccl and os.environ.get("MGS_NATIVE_RCCL", "1") != "0"
+        self.native = bool(native) and self._enable_native(log)
         return self
+
+    # ---- native RCCL transport: the C++ cycle packs, exchanges (ncclSend/ncclRecv) and gathers the tail by itself
+    def _enable_native(self, log=None):
+        """Creates the library's own RCCL communicator (unique id shipped through torch.distributed), hands every
+        sharded level's plan and the tail to the C++ cycle, and cross-checks one native halo exchange per level
+        against the torch.distributed path bit for bit on every rank.  Any failure on any rank → all ranks stay
+        on the callback path (returns False)."""
+        t, comm, ctx = self.torch, self.comm, self.ctx
+        ok = True
+        try:
+            path = os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so").encode()
+            idbuf = C.create_string_buffer(128)
+            if comm.rank == 0:
+                check(lib().mgs_comm_unique_id(ctx.h, path, idbuf), ctx.h)
+            box = [idbuf.raw]
+            comm.dist.broadcast_object_list(box, src=0)
+            idbuf = C.create_string_buffer(box[0], 128)
+            c = C.c_void_p()
+            check(lib().mgs_comm_create(ctx.h, path, idbuf, comm.world, comm.rank, C.byref(c)), ctx.h)
+            self._ncomm = c
+            ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.c_void_p)  # noqa: E731
+            keep = []
+            for l, plan in enumerate(self.plans):
+                idx = np.concatenate(plan.send_idx).astype(np.int32) if plan.send_idx else np.zeros(0, np.int32)
+                sc = np.asarray(plan.send_counts, dtype=np.int32); rc = np.asarray(plan.recv_counts, dtype=np.int32)
+                keep += [idx, sc, rc]
+                check(lib().mgs_hier_set_native_exchange(self.h.h, l, c, ip(idx) if idx.size else None, ip(sc), ip(rc)), ctx.h)
+            nl = np.ascontiguousarray(self.tail_nlocs, dtype=np.int32)
+            check(lib().mgs_hier_set_native_tail(self.h.h, c, self.tail.h, nl.ctypes.data_as(C.c_void_p)), ctx.h)
+            # cross-check against the torch.distributed exchange
+            for l, plan in enumerate(self.plans):
+                n_ext = plan.n_loc + plan.n_halo
+                xa = ctx.vec(n_ext).rand(seed=1234 + l, offset=comm.rank * 7919); xb = ctx.vec(n_ext)
+                check(lib().mgs_vec_copy(xa.h, xb.h), ctx.h)
+                self._exchange(l, xa.ptr)
+                check(lib().mgs_hier_native_halo(self.h.h, l, C.c_void_p(xb.ptr)), ctx.h)
+                ctx.sync(); t.cuda.synchronize()
+                if not np.array_equal(xa.numpy(), xb.numpy()):
+                    ok = False
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            if log:
+                log(f"native RCCL transport unavailable on this rank: {e!r}")
+        flag = np.array([1.0 if ok else 0.0])
+        comm.allreduce_host(flag, op="min")
+        ok = bool(flag[0] > 0.5)
+        if not ok:
+            for l in range(len(self.plans)):
+                try:
+                    lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
+                except Exception:  # noqa: BLE001
+                    pass
+            lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
+        if log:
+            log("exchange transport: " + ("native RCCL inside the C++ cycle (verified against torch.distributed)" if ok else "torch.distributed callbacks"))
+        return ok
 
     def _build_tail(self, ktg, npass, tou, coarse_rows, log):
         """gather the last sharded level and replicate the rest of the hierarchy on every GPU"""
@@ -407,8 +466,23 @@ class ShardedHierarchy:
         return self.h.vcycle(b, x, zero_guess)
 
     def spmv(self, x, y):
-        self._exchange(0, x.ptr)
+        if getattr(self, "native", False):
+            check(lib().mgs_hier_native_halo(self.h.h, 0, C.c_void_p(x.ptr)), self.ctx.h)
+        else:
+            self._exchange(0, x.ptr)
         return self.A.spmv(x, y)
+
+    def close(self):
+        """drop the native plans and the library's communicator (the hierarchy itself is freed with the object)"""
+        c = getattr(self, "_ncomm", None)
+        if c is not None and self.ctx.h:
+            self.ctx.sync()
+            for l in range(len(self.plans)):
+                lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
+            lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
+            lib().mgs_comm_destroy(c)
+            self._ncomm = None
+            self.native = False
 
     def install_allreduce(self):
         self.ctx.set_allreduce(lambda a: self.comm.allreduce_host(a))
@@ -488,7 +562,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"poisson3d_{N}^3_7pt (BASELINE.json configs[4]) row-sharded by plane ranges; V({args.nu1},{args.nu2}) "
                                       f"damped-Jacobi cycle, omega={args.omega}, device-built hierarchy ktg={args.ktg} npass={args.npass} tou={args.tou}",
-                          "grid": N, "rows": n, "nnz": nnz, "parallelism": f"row-shard x{world} (RCCL halo all_to_all, replicated coarse tail)",
+                          "grid": N, "rows": n, "nnz": nnz, "parallelism": f"row-shard x{world} (" + ("native RCCL send/recv inside the C++ cycle" if sh.native else "torch.distributed all_to_all callbacks") + ", replicated coarse tail)",
                           "sharded_levels": len(sh.plans), "total_levels": sh.nlev, "setup_seconds": t_setup},
                "spmv_hbm_gbps": spmv_bytes(n, nnz) / (ms_x * 1e-3) / 1e9,
                "roofline": {"bound": "hbm", "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0, "traffic": None,
@@ -502,6 +576,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                "cpu_baseline": None}
         (emit_json or (lambda o: print(json.dumps(o), flush=True)))(out)
     dist.barrier()
+    sh.close()
     del sh, b, x, xs, y, A
     ctx.close()
     dist.destroy_process_group()

@@ -51,6 +51,25 @@ def main():
     a = np.array([1.5, -2.0]); comm.allreduce_host(a); assert a.tolist() == [1.5, -2.0]
     assert comm.allgather_ints(7).tolist() == [7]
     lists = comm.exchange_lists([np.arange(5, dtype=np.int64)]); assert lists[0].tolist() == [0, 1, 2, 3, 4]
+    # native RCCL transport inside the C++ cycle (self-exchange of a middle slab: every call the N>1 run makes, on one
+    # GPU): must reproduce the torch.distributed callback path bit for bit, cycle and Krylov solve
+    N = 48; lo, hi = 16, 32; n2 = N * N; n_loc = (hi - lo) * n2
+    A = ctx.poisson3d(N, lo, hi, local_cols=True)
+    ids = np.concatenate([np.arange(n_loc - n2, n_loc), np.arange(0, n2)]).astype(np.int32)
+    res = {}
+    for native in (True, False):
+        shh = mgd.ShardedHierarchy(ctx, A, mgd.LevelPlan(n_loc, [ids], [ids]), 0.6, 1, 1, comm)
+        shh.overlap_min_rows = 0; ctx.set_option("split_min_rows", 0)
+        shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=native)
+        assert shh.native == native and len(shh.plans) >= 3, (shh.native, len(shh.plans))
+        b = ctx.vec(n_loc).rand(seed=5); xx = ctx.vec(A.shape[1])
+        shh.vcycle(b, xx)
+        xs = ctx.vec(A.shape[1]).rand(seed=6); ys = ctx.vec(n_loc); shh.spmv(xs, ys)
+        xsol = ctx.vec(A.shape[1]); st, it, tol = shh.bicgstab(xsol, b, 200, 1e-9)
+        res[native] = (xx.numpy(n_loc), ys.numpy(), st, it, xsol.numpy(n_loc))
+        shh.close(); del shh, b, xx, xs, ys, xsol
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert res[True][2] == 0 and res[True][2:4] == res[False][2:4] and np.array_equal(res[True][4], res[False][4]), (res[True][2:4], res[False][2:4])
     print("NCCL_W1_OK")
     ctx.close()
     dist.destroy_process_group()
