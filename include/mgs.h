@@ -293,6 +293,9 @@ int mgs_comm_size(const mgs_comm *c, int *world, int *rank);
 int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int *send_idx, const int *send_counts, const int *recv_counts);
 int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs);
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev);
+/* inner products of the Krylov solvers summed over the ranks with ncclAllReduce on the context's stream (NULL: off;
+ * takes precedence over the mgs_ctx_set_allreduce callback) */
+int mgs_ctx_set_native_allreduce(mgs_ctx *ctx, mgs_comm *c);
 
 /* Builds the pattern code of A's column array (one byte per row + a small table per 256-row block) so the
  * SpMV-shaped kernels stream 8 instead of 12 bytes per entry wherever rows repeat their shape (stencil-like

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "mgs_hier_set_native_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_set_native_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_native_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mgs_ctx_set_native_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgs_csr_optimize": (C.c_int, [C.c_void_p]),
     "mgs_hier_fused_info": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "mgs_csr_rowcode_info": (C.c_int, [C.c_void_p, c_i64_p]),

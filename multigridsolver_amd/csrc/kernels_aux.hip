@@ -456,10 +456,11 @@ int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 1));   // sum over the row shards, on this stream
   MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out_host = ctx->red_host[0];
-  if (ctx->allreduce) {
+  if (ctx->allreduce && !ctx->ncomm) {
     int rc = ctx->allreduce(ctx->allreduce_user, out_host, 1);
     if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
   }
@@ -472,10 +473,11 @@ int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const doub
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
   MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
-  if (ctx->allreduce) {
+  if (ctx->allreduce && !ctx->ncomm) {
     int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
     if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
   }
@@ -487,10 +489,11 @@ int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, 
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(update_dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
   MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
-  if (ctx->allreduce) {
+  if (ctx->allreduce && !ctx->ncomm) {
     int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
     if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
   }

@@ -84,6 +84,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   return MGS_OK;
 }
+int mgs_ctx_set_native_allreduce(mgs_ctx *ctx, mgs_comm *c) { ctx->ncomm = c; return MGS_OK; }
 int mgs_ctx_set_allreduce(mgs_ctx *ctx, mgs_allreduce_fn fn, void *user) { ctx->allreduce = fn; ctx->allreduce_user = user; return MGS_OK; }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  struct mgs_comm *ncomm = nullptr;   // native RCCL all-reduce of the inner products (takes precedence over the callback)
   mgs_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
 };

@@ -480,12 +480,15 @@ class ShardedHierarchy:
             for l in range(len(self.plans)):
                 lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
             lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
+            lib().mgs_ctx_set_native_allreduce(self.ctx.h, None)
             lib().mgs_comm_destroy(c)
             self._ncomm = None
             self.native = False
 
     def install_allreduce(self):
         self.ctx.set_allreduce(lambda a: self.comm.allreduce_host(a))
+        if getattr(self, "native", False):
+            check(lib().mgs_ctx_set_native_allreduce(self.ctx.h, self._ncomm), self.ctx.h)
 
     def bicgstab(self, x, b, max_iter=1000, tol=1e-10):
         self.install_allreduce()
