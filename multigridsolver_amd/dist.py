@@ -355,54 +355,82 @@ class ShardedHierarchy:
         against the torch.distributed path bit for bit on every rank.  Any failure on any rank → all ranks stay
         on the callback path (returns False)."""
         t, comm, ctx = self.torch, self.comm, self.ctx
+
+        def agree(flag):
+            """every collective step below is entered by all ranks or by none"""
+            f = np.array([1.0 if flag else 0.0]); comm.allreduce_host(f, op="min"); return bool(f[0] > 0.5)
+
         ok = True
-        try:
-            path = os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so").encode()
-            idbuf = C.create_string_buffer(128)
-            if comm.rank == 0:
-                check(lib().mgs_comm_unique_id(ctx.h, path, idbuf), ctx.h)
-            box = [idbuf.raw]
-            comm.dist.broadcast_object_list(box, src=0)
-            idbuf = C.create_string_buffer(box[0], 128)
-            c = C.c_void_p()
+        # the RCCL copy this process already uses (torch's); MGS_LIBRCCL overrides the path
+        path = os.environ.get("MGS_LIBRCCL", os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")).encode()
+        idbuf = C.create_string_buffer(128)
+        try:      # local preflight on every rank: the library resolves RCCL and can mint an id
+            check(lib().mgs_comm_unique_id(ctx.h, path, idbuf), ctx.h)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            if log:
+                log(f"native RCCL transport unavailable on this rank: {e!r}")
+        if not agree(ok):
+            if log:
+                log("exchange transport: torch.distributed callbacks")
+            return False
+        box = [idbuf.raw]
+        comm.dist.broadcast_object_list(box, src=0)            # rank 0's id
+        idbuf = C.create_string_buffer(box[0], 128)
+        def fail(stage, e=None):
+            if log:
+                log(f"native RCCL transport: {stage} failed" + (f" ({e!r})" if e is not None else "") + " -> torch.distributed callbacks")
+            self._drop_native()
+            return False
+
+        c = C.c_void_p()
+        try:      # collective: every rank is here
             check(lib().mgs_comm_create(ctx.h, path, idbuf, comm.world, comm.rank, C.byref(c)), ctx.h)
             self._ncomm = c
+        except Exception as e:  # noqa: BLE001
+            ok = False; err = e
+        if not agree(ok):
+            return fail("communicator creation", locals().get("err"))
+        try:      # local: plans and tail into the C++ cycle
             ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.c_void_p)  # noqa: E731
-            keep = []
             for l, plan in enumerate(self.plans):
                 idx = np.concatenate(plan.send_idx).astype(np.int32) if plan.send_idx else np.zeros(0, np.int32)
                 sc = np.asarray(plan.send_counts, dtype=np.int32); rc = np.asarray(plan.recv_counts, dtype=np.int32)
-                keep += [idx, sc, rc]
                 check(lib().mgs_hier_set_native_exchange(self.h.h, l, c, ip(idx) if idx.size else None, ip(sc), ip(rc)), ctx.h)
             nl = np.ascontiguousarray(self.tail_nlocs, dtype=np.int32)
             check(lib().mgs_hier_set_native_tail(self.h.h, c, self.tail.h, nl.ctypes.data_as(C.c_void_p)), ctx.h)
-            # cross-check against the torch.distributed exchange
-            for l, plan in enumerate(self.plans):
+        except Exception as e:  # noqa: BLE001
+            ok = False; err = e
+        if not agree(ok):
+            return fail("plan hand-over", locals().get("err"))
+        # collective: one native halo exchange per level against the torch.distributed exchange, bit for bit
+        for l, plan in enumerate(self.plans):
+            try:
                 n_ext = plan.n_loc + plan.n_halo
                 xa = ctx.vec(n_ext).rand(seed=1234 + l, offset=comm.rank * 7919); xb = ctx.vec(n_ext)
                 check(lib().mgs_vec_copy(xa.h, xb.h), ctx.h)
                 self._exchange(l, xa.ptr)
                 check(lib().mgs_hier_native_halo(self.h.h, l, C.c_void_p(xb.ptr)), ctx.h)
                 ctx.sync(); t.cuda.synchronize()
-                if not np.array_equal(xa.numpy(), xb.numpy()):
-                    ok = False
-        except Exception as e:  # noqa: BLE001
-            ok = False
-            if log:
-                log(f"native RCCL transport unavailable on this rank: {e!r}")
-        flag = np.array([1.0 if ok else 0.0])
-        comm.allreduce_host(flag, op="min")
-        ok = bool(flag[0] > 0.5)
-        if not ok:
-            for l in range(len(self.plans)):
-                try:
-                    lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
-                except Exception:  # noqa: BLE001
-                    pass
-            lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
+                same = bool(np.array_equal(xa.numpy(), xb.numpy()))
+            except Exception as e:  # noqa: BLE001
+                same = False; err = e
+            if not agree(same):
+                return fail(f"cross-check of the level-{l} exchange", locals().get("err"))
         if log:
-            log("exchange transport: " + ("native RCCL inside the C++ cycle (verified against torch.distributed)" if ok else "torch.distributed callbacks"))
-        return ok
+            log("exchange transport: native RCCL inside the C++ cycle (verified against torch.distributed)")
+        return True
+
+    def _drop_native(self):
+        for l in range(len(self.plans)):
+            lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
+        lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
+        lib().mgs_ctx_set_native_allreduce(self.ctx.h, None)
+        c = getattr(self, "_ncomm", None)
+        if c is not None:
+            lib().mgs_comm_destroy(c)
+            self._ncomm = None
+        self.native = False
 
     def _build_tail(self, ktg, npass, tou, coarse_rows, log):
         """gather the last sharded level and replicate the rest of the hierarchy on every GPU"""
@@ -474,16 +502,9 @@ class ShardedHierarchy:
 
     def close(self):
         """drop the native plans and the library's communicator (the hierarchy itself is freed with the object)"""
-        c = getattr(self, "_ncomm", None)
-        if c is not None and self.ctx.h:
+        if getattr(self, "_ncomm", None) is not None and self.ctx.h:
             self.ctx.sync()
-            for l in range(len(self.plans)):
-                lib().mgs_hier_set_native_exchange(self.h.h, l, None, None, None, None)
-            lib().mgs_hier_set_native_tail(self.h.h, None, None, None)
-            lib().mgs_ctx_set_native_allreduce(self.ctx.h, None)
-            lib().mgs_comm_destroy(c)
-            self._ncomm = None
-            self.native = False
+            self._drop_native()
 
     def install_allreduce(self):
         self.ctx.set_allreduce(lambda a: self.comm.allreduce_host(a))

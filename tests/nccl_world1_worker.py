@@ -70,6 +70,15 @@ def main():
         shh.close(); del shh, b, xx, xs, ys, xsol
     assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
     assert res[True][2] == 0 and res[True][2:4] == res[False][2:4] and np.array_equal(res[True][4], res[False][4]), (res[True][2:4], res[False][2:4])
+    # a rank that cannot resolve RCCL: every rank falls back to the callback path, the cycle still runs
+    os.environ["MGS_LIBRCCL"] = "/nonexistent/librccl.so"
+    shh = mgd.ShardedHierarchy(ctx, A, mgd.LevelPlan(n_loc, [ids], [ids]), 0.6, 1, 1, comm)
+    shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=True)
+    assert shh.native is False
+    b = ctx.vec(n_loc).rand(seed=5); xx = ctx.vec(A.shape[1]); shh.vcycle(b, xx)
+    assert np.array_equal(xx.numpy(n_loc), res[False][0])
+    shh.close(); del shh, b, xx
+    del os.environ["MGS_LIBRCCL"]
     print("NCCL_W1_OK")
     ctx.close()
     dist.destroy_process_group()
