@@ -362,13 +362,14 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
   const int tid = threadIdx.x;
   const int lo = blkptr[blk], hi = blkptr[blk + 1];
   const int t0 = tptr[blk], tlen = tptr[blk + 1] - t0;
+  const int capi_abs = capi < 0 ? -capi : capi;
   double *__restrict__ vals = lds_raw;                                    // capv + 2 doubles
   int *__restrict__ ints = reinterpret_cast<int *>(lds_raw + capv + 2);   // capi ints: the block's table, or its index slice
   const int row = r0 + tid;
   const int start = lo & ~1;
   const int nent = hi - start;
-  const bool coded = tlen > 0 && tlen <= capi;
-  const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi);     // block-uniform
+  const bool coded = tlen > 0 && tlen <= capi_abs;
+  const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi_abs);     // block-uniform
   int ga = 0, ge = 0, base = row;
   double bi = 0.0, di = 0.0, xi = 0.0, pei = 0.0;
   if (row < r1) {
@@ -437,10 +438,12 @@ __global__ __launch_bounds__(RB) void csr_rowblock_coded_kernel(
     }
   }
   if (row < r1) {
-    if (OP == MGS_OP_SPMV) out[row] = s;
-    else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
-    else if (OP == MGS_OP_JACOBI) out[row] = xi + (omega * di) * (bi - s);
-    else out[row] = (xi + pei) + di * (bi - s);
+    double v;
+    if (OP == MGS_OP_SPMV) v = s;
+    else if (OP == MGS_OP_RESIDUAL) v = bi - s;
+    else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
+    else v = (xi + pei) + di * (bi - s);
+    if (capi < 0) __builtin_nontemporal_store(v, out + row); else out[row] = v;   // capi < 0: streaming store (A/B option nt_store)
   }
 }
 
@@ -888,7 +891,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define C_(O, UU, H) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
-                                        c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, capi, bm, A->blkptr, hv, split)
+                                        c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split)
 #define CH_(O, UU) do { if (hv) C_(O, UU, true); else C_(O, UU, false); } while (0)
 #define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)
   switch (op) {

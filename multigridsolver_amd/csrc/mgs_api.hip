@@ -79,6 +79,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
   else if (k == "fuse_operands") ctx->opt_fuse_operands = value;
   else if (k == "rowcode") ctx->opt_rowcode = value;
+  else if (k == "nt_store") ctx->opt_nt_store = value;
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
@@ -814,7 +815,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
   const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse && !h->native && !h->ntail;
-  const int gkey = ctx->opt_fuse * 4 + ctx->opt_fuse_operands * 2 + ctx->opt_rowcode;
+  const int gkey = ctx->opt_fuse * 8 + ctx->opt_fuse_operands * 4 + ctx->opt_rowcode * 2 + ctx->opt_nt_store;
   if (h->graph_fuse != gkey) drop_graph(h);
   h->graph_fuse = gkey;
   if (!use_graph) {

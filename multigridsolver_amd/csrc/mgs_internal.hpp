@@ -29,6 +29,7 @@ struct mgs_ctx {
   int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_nt_store = 0;  // streaming (non-temporal) stores of the kernel outputs (A/B)
   int opt_split_min_rows = 400000;   // row shards: levels with fewer owned rows exchange first and launch once (no interior/boundary split)
   int opt_rowcode = 1;   // pattern-coded index (8 B per entry streamed instead of 12 where rows repeat their shape)
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)

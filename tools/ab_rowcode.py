@@ -23,3 +23,12 @@ for rnd in range(2):
         tv = h.time_vcycle(b, y, reps=20) if hasattr(h, "time_vcycle") else float("nan")
         print(f"rowcode={rc}: " + " ".join(f"{k} {v:.3f} ms" for k, v in res.items()) + f" | vcycle {tv:.3f} ms", flush=True)
 ctx.set_option("rowcode", 1)
+for rnd in range(2):
+    for nts in (0, 1):
+        ctx.set_option("nt_store", nts)
+        res = {}
+        for op, name in ((mg.OP_SPMV, "spmv"), (mg.OP_RESIDUAL, "residual"), (mg.OP_JACOBI, "jacobi")):
+            res[name] = A.time_kernel(op, x, b=b, dinv=d, out=y, reps=20)
+        tv = h.time_vcycle(b, y, reps=20)
+        print(f"nt_store={nts}: " + " ".join(f"{k} {v:.3f} ms" for k, v in res.items()) + f" | vcycle {tv:.3f} ms", flush=True)
+ctx.set_option("nt_store", 0)
