@@ -344,7 +344,8 @@ class ShardedHierarchy:
         if fused:
             self.h.set_halo_exchange_fused(self._exchange_fused)
         if native is None:
-            native = comm.nccl and os.environ.get("MGS_NATIVE_RCCL", "1") != "0"
+            env = os.environ.get("MGS_NATIVE_RCCL", "1")      # "force": also without the nccl backend (tests: MGS_LIBRCCL → stand-in)
+            native = env == "force" or (comm.nccl and env != "0")
         self.native = bool(native) and self._enable_native(log)
         return self
 

@@ -48,6 +48,8 @@ def main():
     ctx.set_option("split_min_rows", 0 if N != 24 else 400000)   # ... and the interior/boundary split (N = 24: the exchange-then-one-launch form)
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap, fused=fused)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
+    if os.environ.get("MGS_NATIVE_RCCL") == "force":
+        assert sh.native, "native transport was requested but the build fell back to callbacks"
     if not mtx:
         n2 = N * N
     bg = orc.rand_rhs(nglob)

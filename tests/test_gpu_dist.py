@@ -24,6 +24,23 @@ def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world,N,tail", [(2, 20, 1500), (3, 18, 800), (4, 18, 600), (2, 40, 3000)])
+def test_native_transport_multi_rank_matches_oracle(world, N, tail):
+    """the NATIVE transport of the C++ cycle (ncclSend/ncclRecv groups, tail all-gather, all-reduced dots) with several
+    ranks on this one GPU: RCCL's entry points are served by tests/fake_rccl (file-based stand-in, real RCCL refuses
+    two ranks per device), everything above them — plan hand-over, pack kernels, peer offsets, uneven tail shards
+    (world 4 on 18 planes) — is the code of the N-GPU run; cycle vs the oracle, solve to 1e-10."""
+    fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    port = 29650 + (os.getpid() % 1000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_general_operator_matches_oracle(world, inputs):
     """a bundled, nonsymmetric operator (CSky3d30) sharded by contiguous row ranges with the generic halo plan
