@@ -52,6 +52,19 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
   if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16) != hipSuccess) {
     delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
   }
+  // MGS_OPTIONS="key=value,key=value": initial option values of every context (A/B runs of whole test suites)
+  if (const char *env = getenv("MGS_OPTIONS")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos); if (end == std::string::npos) end = all.size();
+      const std::string kv = all.substr(pos, end - pos); const size_t eq = kv.find('=');
+      if (eq != std::string::npos && mgs_ctx_set_option(c, kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) != MGS_OK) {
+        const std::string msg = g_mgs_last_error; mgs_ctx_destroy(c); return mgs_fail(nullptr, MGS_ERR_INVALID, "MGS_OPTIONS: %s", msg.c_str());
+      }
+      pos = end + 1;
+    }
+  }
   *out = c;
   return MGS_OK;
 }

@@ -56,7 +56,7 @@ def main():
     b = ctx.vec(bg[lo * n2: hi * n2]); x = ctx.vec(n_ext)
     sh.vcycle(b, x)
     x_loc = x.numpy(n_loc)
-    if fused and not mtx and N >= 40:
+    if fused and not mtx and N >= 40 and not os.environ.get("MGS_OPTIONS"):
         # the shard runs the fused passes on their setup-time operands with pattern-coded, halo-tagged indices
         fi = sh.h.fused_info(0)
         assert fi["has_val_wd"] and fi["has_col_agg"] and fi["coded_col_halo"] >= 0.9 * fi["blocks"] and fi["coded_col_agg"] >= 0.5 * fi["blocks"], fi
