@@ -250,6 +250,10 @@ class ShardedHierarchy:
     def _prepare_plan(self, level):
         t = self.torch
         plan = self.plans[level]
+        rows, cols = (self.A if level == 0 else self.h.level_A(level)).shape
+        if plan.n_loc != rows or plan.n_halo != cols - rows or any(len(a) and (a.min() < 0 or a.max() >= rows) for a in plan.send_idx):
+            raise ValueError(f"halo plan of level {level} does not fit its shard: plan {plan.n_loc} rows + {plan.n_halo} halo slots, "
+                             f"operator {rows} x {cols}")
         idx = np.concatenate(plan.send_idx) if plan.send_idx else np.zeros(0, np.int32)
         plan.dev_send_idx = t.from_numpy(idx.astype(np.int32)).to(self.comm.device)
         self._bufs[level] = t.empty(max(len(idx), 1), dtype=t.float64, device=self.comm.device)

@@ -24,7 +24,11 @@ comm = mgd.Comm()
 lo, hi = mgd.plane_range(N, R, R // 2)
 n2 = N * N; n_loc = (hi - lo) * n2
 A = ctx.poisson3d(N, lo, hi, local_cols=True)
-ids = np.concatenate([np.arange(n_loc - n2, n_loc), np.arange(0, n2)]).astype(np.int32)   # lower halo <- my last plane, upper <- my first
+if R >= 3:
+    ids = np.concatenate([np.arange(n_loc - n2, n_loc), np.arange(0, n2)]).astype(np.int32)   # lower halo <- my last plane, upper <- my first
+else:                 # two ranks: rank 1 has a lower neighbour only
+    ids = np.arange(n_loc - n2, n_loc).astype(np.int32)
+assert A.shape[1] - A.shape[0] == ids.size, "emulated plan does not fit the slab"
 plan = mgd.LevelPlan(n_loc, [ids], [ids])
 configs = ((True, True, True),) if os.environ.get("EMU_ONE") else ((True, True, True), (True, True, False), (False, True, False), (True, False, False))
 for overlap, fused, native in configs:
