@@ -874,9 +874,11 @@ void mgs_free_rowcode(mgs_rowcode *c) {
 }
 
 // true when the coded kernel serves this operator (square or sharded; short rows; code present and worth it)
-static bool use_rowcode(const mgs_csr *A, const mgs_rowcode *c) {
+// (any = true: a row shard's operand passes — only this kernel knows the halo split, and on its uncoded blocks it is the
+//  slice kernel: any code will do)
+static bool use_rowcode(const mgs_csr *A, const mgs_rowcode *c, bool any = false) {
   return c && A->ctx->opt_rowcode && A->blkptr && A->lds_cap > 0 && A->max_row_len <= 64 &&
-         (double)c->coded_blocks >= 0.5 * c->nblocks;
+         (any || (double)c->coded_blocks >= 0.5 * c->nblocks);
 }
 // op ∈ {SPMV, RESIDUAL, JACOBI, FUSE_POST_MAPPED}; for the post pass: x = e_c, b = r, dinv = wd, xin = b, idx = agg[col]
 static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const int *idx, const double *x, const double *b, const double *dinv,
@@ -908,7 +910,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   return MGS_OK;
 }
 
-bool mgs_rowcode_usable(const mgs_csr *A) { return use_rowcode(A, A->code); }
+bool mgs_rowcode_usable(const mgs_csr *A, bool any) { return use_rowcode(A, A->code, any); }
 
 // workgroup → row-block map of a launch over the row blocks [blk_lo, blk_hi) (XCD-contiguous, strip-major for far bands)
 static dim3 plan_block_map(const mgs_csr *A, int blk_lo, int blk_hi, BlockMap &bm) {
@@ -934,7 +936,7 @@ int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const doub
                            const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,
                            int gap_at, int gap_len) {
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
-  if (!use_rowcode(A, A->code)) return MGS_ERR_STATE;
+  if (!use_rowcode(A, A->code, hv != nullptr)) return MGS_ERR_STATE;
   BlockMap bm;
   const dim3 grid = plan_block_map(A, blk_lo, blk_hi, bm);
   bm.gap_at = gap_at; bm.gap_len = gap_len;

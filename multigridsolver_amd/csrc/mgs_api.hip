@@ -713,7 +713,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false; if (halo) Ahat.code = L.code_pre;
     mgs_csr Amap = *L.A; Amap.val = L.A->val; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
     const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
-                          (!halo || (mgs_rowcode_usable(&Ahat) && mgs_rowcode_usable(&Amap)));
+                          (!halo || (mgs_rowcode_usable(&Ahat, true) && mgs_rowcode_usable(&Amap, true)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
                           const double *dv, const double *xin, const int *agg, double *out, int isplit) -> int {
       if (L.nx) {      // native RCCL exchange of the payload on this stream, then one launch

@@ -208,7 +208,7 @@ int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *id
 int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);
 int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out);
-bool mgs_rowcode_usable(const mgs_csr *A);
+bool mgs_rowcode_usable(const mgs_csr *A, bool any = false);
 int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
                            const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,
                            int gap_at = 0x7fffffff, int gap_len = 0);
