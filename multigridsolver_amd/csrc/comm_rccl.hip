@@ -96,12 +96,15 @@ int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *
   hipStream_t s = c->ctx->stream;
   MGS_NCCL(c, c->GroupStart());
   size_t so = 0, ro = 0;
-  for (int p = 0; p < c->world; ++p) {
-    if (scnt[p]) MGS_NCCL(c, c->Send(send + so, (size_t)scnt[p], ncclDouble, p, c->comm, s));
-    if (rcnt[p]) MGS_NCCL(c, c->Recv(recv + ro, (size_t)rcnt[p], ncclDouble, p, c->comm, s));
+  ncclResult_t bad = ncclSuccess;
+  for (int p = 0; p < c->world && bad == ncclSuccess; ++p) {
+    if (scnt[p]) bad = c->Send(send + so, (size_t)scnt[p], ncclDouble, p, c->comm, s);
+    if (rcnt[p] && bad == ncclSuccess) bad = c->Recv(recv + ro, (size_t)rcnt[p], ncclDouble, p, c->comm, s);
     so += (size_t)scnt[p]; ro += (size_t)rcnt[p];
   }
-  MGS_NCCL(c, c->GroupEnd());
+  const ncclResult_t end = c->GroupEnd();          // always closed, also after a failed post
+  if (bad != ncclSuccess) return mgs_fail(c->ctx, MGS_ERR_STATE, "ncclSend/ncclRecv failed: %s", c->GetErrorString(bad));
+  if (end != ncclSuccess) return mgs_fail(c->ctx, MGS_ERR_STATE, "ncclGroupEnd failed: %s", c->GetErrorString(end));
   return MGS_OK;
 }
 int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count) {
