@@ -67,6 +67,34 @@ def pmc_traffic(kernel="spmv", grid=512):
     return best
 
 
+def optin_value_patterns(mg, args, N):
+    """NOT the headline: the same cycle with the opt-in option valcode = 1 (pattern tuples carry the values, coded row
+    blocks stream no matrix entry).  It pays only because this synthetic operator has constant coefficients — a
+    variable-coefficient operator falls back to the default path — so it is reported beside `value`, never as it."""
+    ctx = mg.Context(0)
+    try:
+        ctx.set_option("valcode", 1)
+        n = N ** 3
+        A = ctx.poisson3d(N)
+        h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+        b = ctx.vec(n).rand(seed=0); x = ctx.vec(n); xs = ctx.vec(n).rand(seed=1); y = ctx.vec(n)
+        for _ in range(3):
+            h.vcycle(b, x)
+        A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
+        ms_spmv = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=args.kernel_reps)
+        ms_cycle = h.time_vcycle(b, x, reps=args.steps)
+        code = A.rowcode_info()
+        out = {"option": "valcode=1 (opt-in, off by default)", "vcycles_per_s": 1e3 / ms_cycle, "ms_per_vcycle": ms_cycle, "spmv_ms": ms_spmv,
+               "spmv_streamed_bytes": 21 * n + 12 * code["table_ints"] + 8 * (code["blocks"] + 1),
+               "coded_row_blocks": code["coded_blocks"], "row_blocks": code["blocks"],
+               "note": "same bits as the default path (tests/test_gpu_parity.py::test_value_pattern_coding_bit_identical); benefits only operators "
+                       "whose rows repeat index shape AND values (constant / piecewise-constant coefficients)"}
+        del h, A, b, x, xs, y
+        return out
+    finally:
+        ctx.close()
+
+
 def bundled_cases(mg, args):
     """V-cycles/s on the reference's bundled operators (BASELINE.json configs[1..2]; cache-resident,
     launch-latency bound — reported as time, not as an HBM fraction)."""
@@ -358,6 +386,11 @@ def main():
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
+    try:
+        out["optin_value_patterns"] = optin_value_patterns(mg, args, N)
+        log(f"opt-in value patterns (not the headline): {out['optin_value_patterns']['vcycles_per_s']:.1f} V-cycles/s, SpMV {out['optin_value_patterns']['spmv_ms']:.3f} ms")
+    except Exception as e:  # noqa: BLE001
+        log("opt-in value-pattern leg failed:", repr(e))
     try:
         out["bundled_matrices"] = bundled_cases(mg, args)
     except Exception as e:  # noqa: BLE001

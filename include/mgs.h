@@ -310,7 +310,8 @@ int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]);
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements (initial values of every context: environment MGS_OPTIONS="key=value,...").  key: "spmv_variant", "xcd_remap", "nontemporal",
- * "graph", "strip", "fuse", "nt_store" (streaming stores, measured neutral), "rowcode" (pattern-coded index, default 1), "split_min_rows" (row shards: smallest level that
+ * "graph", "strip", "fuse", "nt_store" (streaming stores, measured neutral), "valcode" (opt-in: pattern tuples carry the values too, set before
+ * mgs_csr_optimize / the hierarchy is built; pays only where coefficients repeat), "rowcode" (pattern-coded index, default 1), "split_min_rows" (row shards: smallest level that
  * overlaps its halo exchange with interior row blocks, default 400000), "fuse_operands" (setup-time operands of the fused cycle passes,
  * +12 B of HBM per matrix entry; default 1), "lds_pad", "blkptr".  Unknown key: MGS_ERR_INVALID. */
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);

@@ -345,14 +345,15 @@ constexpr int CODE_NEG = (int)0x80000000;   // table word of a negative index (c
 constexpr int CODE_HALO = 0x60000000, CODE_HALO_LO = 0x50000000, CODE_OFF_MAX = 0x40000000;
 
 // (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
-template <int OP, int U, bool HALO>
+// VAL: the tuples carry the values as well (`vtab`, option valcode): a coded block then streams no matrix entry at all.
+template <int OP, int U, bool HALO, bool VAL>
 __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblock_coded_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x /*gather source: x, or e_c for the post pass*/, const double *__restrict__ b /*b, or r for the post pass*/,
     const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
     const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,
-    const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split) {
+    const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int vb = map_block(bm, blockIdx.x);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
   const int row = r0 + tid;
   const int start = lo & ~1;
   const int nent = hi - start;
-  const bool coded = tlen > 0 && tlen <= capi_abs;
+  const bool coded = tlen > 0 && tlen <= capi_abs && (!VAL || tlen <= capv);
   const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi_abs);     // block-uniform
   int ga = 0, ge = 0, base = row;
   double bi = 0.0, di = 0.0, xi = 0.0, pei = 0.0;
@@ -383,8 +384,11 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
   if (staged) {
     const int nch = (nent + 1) >> 1;
     if (coded) {
+      if (VAL) { for (int c = tid; c < tlen; c += RB) vals[c] = vtab[t0 + c]; }     // value tuples instead of the value slice (tlen <= capv)
+      else {
 #pragma unroll 4
-      for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+        for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+      }
       for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
     } else {
 #pragma unroll 4
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
             else xv[q] = (POST && oq[q] == CODE_NEG) ? 0.0 : x[base + oq[q]];
           }
 #pragma unroll
-          for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+          for (int q = 0; q < U; ++q) vq[q] = VAL ? vals[ps + min(j + q, last)] : vals[min(k + q, lim)];
 #pragma unroll
           for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
         }
@@ -461,12 +465,15 @@ __device__ __forceinline__ int code_off(int i, int base, int row, int split) {
 }
 __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
                                                             const int *__restrict__ base, int split, unsigned char *__restrict__ pid,
-                                                            unsigned char *__restrict__ isrep, int *__restrict__ blk_ints) {
+                                                            unsigned char *__restrict__ isrep, int *__restrict__ blk_ints,
+                                                            const double *__restrict__ val /*non-null: tuples include the values*/) {
   __shared__ int s_rep, s_ints, s_np, s_bad;
   const int blk = blockIdx.x, r0 = blk * RB, r1 = min(r0 + RB, n), tid = threadIdx.x, row = r0 + tid;
   const bool valid = row < r1;
   int a = 0, len = 0, bs = 0;
   if (valid) { a = rowptr[row]; len = rowptr[row + 1] - a; bs = base ? base[row] : row; }
+  // table budget: half of what the block streams otherwise (4 B per entry index-only, 12 B with values; a table entry
+  // costs 4 resp. 12 B) → the same entry count either way
   const int budget = (rowptr[r1] - rowptr[r0]) / 2 - 64;
   bool assigned = !valid, rep = false, ok = true;
   int mypid = 0;
@@ -484,6 +491,7 @@ __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__
         const int rr = r0 + r, ra = rowptr[rr], rl = rowptr[rr + 1] - ra, rb = base ? base[rr] : rr;
         same = rl == len;
         for (int j = 0; same && j < len; ++j) same = code_off(idx[a + j], bs, row, split) == code_off(idx[ra + j], rb, rr, split);
+        if (val) for (int j = 0; same && j < len; ++j) same = __double_as_longlong(val[a + j]) == __double_as_longlong(val[ra + j]);   // same bits
       } else {
         rep = true; s_ints += len; s_np = p + 1;
         for (int j = 0; j < len; ++j) if (code_off(idx[a + j], bs, row, split) == CODE_BAD) s_bad = 1;
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(RB) void rowcode_assign_kernel(int n, const int *__
 __global__ __launch_bounds__(RB) void rowcode_fill_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ idx,
                                                           const int *__restrict__ base, int split, const unsigned char *__restrict__ pid,
                                                           const unsigned char *__restrict__ isrep, const int *__restrict__ tptr,
-                                                          int *__restrict__ tab) {
+                                                          int *__restrict__ tab, const double *__restrict__ val, double *__restrict__ vtab) {
   __shared__ int plen[RB], pstart[RB];
   const int blk = blockIdx.x, r0 = blk * RB, r1 = min(r0 + RB, n), tid = threadIdx.x, row = r0 + tid;
   const int t0 = tptr[blk];
@@ -514,6 +522,7 @@ __global__ __launch_bounds__(RB) void rowcode_fill_kernel(int n, const int *__re
   if (rep) {
     tab[t0 + p] = pstart[p];
     for (int j = 0; j < len; ++j) tab[t0 + pstart[p] + j] = code_off(idx[a + j], bs, row, split);
+    if (vtab) for (int j = 0; j < len; ++j) vtab[t0 + pstart[p] + j] = val[a + j];     // same indexing as tab (header slots unused)
   }
 }
 
@@ -820,7 +829,8 @@ int mgs_plan_csr(mgs_csr *A) {
 
 // Builds the pattern code of the index array `idx` (CSR-shaped like rowptr; base = nullptr: offsets from the row;
 // indices >= split address the halo payload of a row shard and are coded as slot − row).
-int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out) {
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out,
+                      const double *val) {
   *out = nullptr;
   if (n <= 0) return MGS_OK;
   const int nblocks = (n + RB - 1) / RB;
@@ -835,7 +845,7 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
   std::vector<int> h((size_t)nblocks + 1, 0);
   if (rc == MGS_OK) {
     hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)nblocks + 1), ctx->stream);
-    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, ints);
+    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, ints, val);
     hipMemcpyAsync(h.data(), ints, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 1 failed");
   }
@@ -853,8 +863,9 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
       c->tab_cap = sizes[(size_t)((sizes.size() - 1) * 0.985)];
       hipMemcpyAsync(c->tptr, h.data(), sizeof(int) * ((size_t)nblocks + 1), hipMemcpyHostToDevice, ctx->stream);
       rc = mgs_dev_alloc(ctx, &c->tab, (size_t)total + 4);
+      if (rc == MGS_OK && val) rc = mgs_dev_alloc(ctx, &c->vtab, (size_t)total + 4);
       if (rc == MGS_OK) {
-        hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, c->tptr, c->tab);
+        hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, c->tptr, c->tab, val, c->vtab);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 2 failed");
       }
     }
@@ -870,6 +881,7 @@ void mgs_free_rowcode(mgs_rowcode *c) {
   if (c->pid) hipFree(c->pid);
   if (c->tptr) hipFree(c->tptr);
   if (c->tab) hipFree(c->tab);
+  if (c->vtab) hipFree(c->vtab);
   delete c;
 }
 
@@ -893,9 +905,10 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const size_t lds = (size_t)(capv + 2) * 8 + (size_t)capi * 4 + 16 + (size_t)ctx->opt_lds_pad;
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
-#define C_(O, UU, H) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
-                                        c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split)
-#define CH_(O, UU) do { if (hv) C_(O, UU, true); else C_(O, UU, false); } while (0)
+#define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
+                                           c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab)
+#define CH_(O, UU) do { if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
+                        else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
 #define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)
   switch (op) {
     case MGS_OP_SPMV: CU_(MGS_OP_SPMV); break;

@@ -93,6 +93,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "fuse_operands") ctx->opt_fuse_operands = value;
   else if (k == "rowcode") ctx->opt_rowcode = value;
   else if (k == "nt_store") ctx->opt_nt_store = value;
+  else if (k == "valcode") ctx->opt_valcode = value;
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
@@ -174,7 +175,7 @@ int mgs_csr_destroy(mgs_csr *A) {
 int mgs_csr_optimize(mgs_csr *A) {
   if (!A || A->code_tried || !A->ctx->opt_rowcode || A->rows == 0 || A->nnz == 0) return MGS_OK;
   A->code_tried = true;
-  return mgs_build_rowcode(A->ctx, A->rows, A->rowptr, A->col, nullptr, 0x7fffffff, &A->code);
+  return mgs_build_rowcode(A->ctx, A->rows, A->rowptr, A->col, nullptr, 0x7fffffff, &A->code, A->ctx->opt_valcode ? A->val : nullptr);
 }
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]) {
   out[0] = A->code ? A->code->coded_blocks : 0; out[1] = A->code ? A->code->nblocks : (A->rows + 255) / 256;
@@ -337,6 +338,7 @@ static void level_free(mgs_level &L) {
   if (L.col_agg) hipFree(L.col_agg);
   mgs_free_rowcode(L.code_agg);
   mgs_free_rowcode(L.code_pre);
+  mgs_free_rowcode(L.code_hat);
   if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
@@ -710,7 +712,9 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     // Setup-time operands: Â = A·diag(wd) makes the pre pass the plain residual kernel with x = b (one gather per
     // entry), col_agg = agg[col] lets the post pass gather e_c directly.  On a shard the halo columns read the
     // payload (x1 resp. Pe of the peers' rows) and only the pattern-coded kernel knows that split.
-    mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false; if (halo) Ahat.code = L.code_pre;
+    // Â's code: its own when the tuples carry values or halo tags, A's index-only code otherwise
+    mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false;
+    Ahat.code = halo ? L.code_pre : ((L.A->code && L.A->code->vtab) || L.code_hat ? L.code_hat : L.A->code);
     mgs_csr Amap = *L.A; Amap.val = L.A->val; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
     const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
                           (!halo || (mgs_rowcode_usable(&Ahat, true) && mgs_rowcode_usable(&Amap, true)));
@@ -798,15 +802,21 @@ static int prepare_fused(mgs_hier *h) {
     if (rescale) { MGS_TRY(k_axpby(ctx, L.n, h->omega, L.dinv->d, 0.0, L.wd->d)); L.wd_omega = h->omega; drop_graph(h); }
     if (ctx->opt_fuse_operands) {      // derived CSR operands of the fused passes (same shape as A)
       const bool shard = L.A->cols > L.A->rows;
-      if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); }
-      else if (rescale) MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd));
+      bool new_vals = false;
+      if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); new_vals = true; }
+      else if (rescale) { MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); new_vals = true; }
       if (!L.col_agg) {
         MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.T->n_coarse, L.col_agg)); drop_graph(h);
-        if (ctx->opt_rowcode) {
-          MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg));
-          // on a shard the pre pass reads b (owned entries only) + the payload: halo columns need tagged table words
-          if (shard) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, L.A->rows, &L.code_pre));
-        }
+        if (ctx->opt_rowcode)
+          MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg,
+                                    ctx->opt_valcode ? L.A->val : nullptr));
+      }
+      // codes whose tuples depend on Â's values (or, on a shard, on the halo tags) follow val_wd
+      if (ctx->opt_rowcode && new_vals && (shard || ctx->opt_valcode)) {
+        mgs_free_rowcode(L.code_pre); L.code_pre = nullptr; mgs_free_rowcode(L.code_hat); L.code_hat = nullptr; drop_graph(h);
+        // on a shard the pre pass reads b (owned entries only) + the payload: halo columns need tagged table words
+        if (shard) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, L.A->rows, &L.code_pre, ctx->opt_valcode ? L.val_wd : nullptr));
+        else MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, 0x7fffffff, &L.code_hat, L.val_wd));
       }
     }
   }

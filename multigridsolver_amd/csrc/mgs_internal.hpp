@@ -29,6 +29,8 @@ struct mgs_ctx {
   int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_valcode = 0;   // pattern tuples include the VALUES (rows with equal index shape and equal values share a tuple): coded blocks stream no
+                         // matrix entry at all.  Pays only where coefficients repeat (constant-coefficient / piecewise-constant operators): opt-in.
   int opt_nt_store = 0;  // streaming (non-temporal) stores of the kernel outputs (A/B)
   int opt_split_min_rows = 400000;   // row shards: levels with fewer owned rows exchange first and launch once (no interior/boundary split)
   int opt_rowcode = 1;   // pattern-coded index (8 B per entry streamed instead of 12 where rows repeat their shape)
@@ -45,6 +47,7 @@ struct mgs_rowcode {
   unsigned char *pid = nullptr;  // n: the row's tuple within its row block's table
   int *tptr = nullptr;           // nblocks+1: table slice of each row block in tab (empty: block keeps its index array)
   int *tab = nullptr;            // per coded block: pstart[npat], then the offset tuples
+  double *vtab = nullptr;        // option valcode: the tuples' values, indexed like tab (rows are one tuple only if index AND values repeat)
   int tab_max = 0, tab_cap = 0;  // largest table / LDS budget covering 98.5 % of the coded blocks (ints)
   int coded_blocks = 0, nblocks = 0;
   int64_t tab_total = 0;
@@ -129,6 +132,7 @@ struct mgs_level {
   int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
   mgs_rowcode *code_pre = nullptr;   // row shards: pattern code of col with tagged halo words (pre pass reads b + payload)
+  mgs_rowcode *code_hat = nullptr;   // option valcode: pattern code of (col, val_wd) for the pre pass on Â
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -207,7 +211,8 @@ int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int
 int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
 int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
 int mgs_plan_csr(mgs_csr *A);
-int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out);
+int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out,
+                      const double *val = nullptr);
 bool mgs_rowcode_usable(const mgs_csr *A, bool any = false);
 int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const double *b, const double *dinv, double omega,
                            const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,

@@ -708,3 +708,38 @@ def test_pattern_coded_rows_bit_identical(ctx, mg, orc):
         ctx.set_option("rowcode", 1)
     assert np.array_equal(y0, y1)
     assert h.level_A(0).rowcode_info()["coded_blocks"] > 0
+
+
+def test_value_pattern_coding_bit_identical(ctx, mg, orc):
+    """option valcode (opt-in): the pattern tuples carry the values too, coded row blocks stream no matrix entry at all.
+    Same products in the same order → same bits as the default path, for kernels and whole cycles, on a constant-coefficient
+    operator (everything coded), a variable-coefficient one (nothing to share → falls back) and after a new ω."""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(3)
+    N = 36; n = N ** 3
+    Po = orc.poisson3d(N)
+    P = sps.csr_matrix((Po.val, Po.col, Po.rowptr), shape=(n, n))
+    V = P.copy(); V.data = V.data * (1.0 + 0.3 * rng.random(V.nnz))          # variable coefficients: no two rows alike
+    for name, M in (("constant", P), ("variable", V)):
+        Ao = orc.Csr.from_scipy(M)
+        x_np = rng.standard_normal(n); b_np = rng.standard_normal(n)
+        res = {}
+        for vc in (0, 1):
+            ctx.set_option("valcode", vc)
+            try:
+                A = dev(ctx, Ao); A.optimize()
+                x = ctx.vec(x_np); b = ctx.vec(b_np)
+                h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=300, max_levels=8).finalize()
+                y = A.spmv(x).numpy(); c1 = h.vcycle(b).numpy()
+                h.set_smoother(0.8, 1, 1); c2 = h.vcycle(b).numpy()
+                res[vc] = (y, c1, c2, A.rowcode_info(), h.fused_info(0))
+                del h, A
+            finally:
+                ctx.set_option("valcode", 0)
+        for q in range(3):
+            assert np.array_equal(res[0][q], res[1][q]), (name, q)
+        assert np.array_equal(res[1][0], Ao.spmv(x_np))
+        if name == "constant":
+            assert res[1][3]["coded_blocks"] >= res[1][3]["blocks"] - 1 and res[1][4]["coded_col_agg"] > 0, res[1][3:]
+        else:
+            assert res[1][3]["coded_blocks"] == 0, res[1][3]

@@ -57,5 +57,20 @@ for t in range(trials):
         ctx.set_option("fuse_operands", 0); cg = h.vcycle(b).numpy(); ctx.set_option("fuse_operands", 1)
         assert np.array_equal(c0, c1), (t, "cycle bits", dim, N)
         assert np.linalg.norm(cg - c1) <= 1e-12 * np.linalg.norm(c1), (t, "operand form", dim, N)
+    # opt-in value patterns: a second copy of the operator built with valcode = 1 must reproduce the same bits
+    ctx.set_option("valcode", 1)
+    try:
+        A2 = ctx.csr(n, n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data); A2.optimize()
+        assert np.array_equal(A2.spmv(x).numpy(), y1) and np.array_equal(A2.residual(x, b).numpy(), r1) and np.array_equal(A2.jacobi(d, 0.7, b, x).numpy(), j1), (t, "valcode kernels")
+        stats["valcoded"] = stats.get("valcoded", 0) + (1 if A2.rowcode_info()["coded_blocks"] else 0)
+        h2 = mg.Hierarchy(A2, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=max(50, n // 60), max_levels=8)
+        if h2.nlev >= 2:
+            h2.finalize()
+            assert np.array_equal(h2.vcycle(b).numpy(), c1), (t, "valcode cycle bits", dim, N)
+            h2.set_smoother(0.9, 1, 1); h.set_smoother(0.9, 1, 1)
+            assert np.array_equal(h2.vcycle(b).numpy(), h.vcycle(b).numpy()), (t, "valcode cycle bits after a new omega", dim, N)
+        del h2, A2
+    finally:
+        ctx.set_option("valcode", 0)
     del h, A, x, b, d
 print("STRESS_OK", trials, stats)
