@@ -18,6 +18,9 @@
 // shuffles.  The workgroup→row-block map is XCD-contiguous (each of the 8 XCDs sweeps one eighth
 // of the rows so re-read x planes stay in that XCD's 4 MiB L2), optionally strip-major.
 // The earlier "products in LDS" variants are kept for A/B runs (tools/ab_spmv.py).
+// Default path for operators whose rows repeat their shape (stencils, their Galerkin levels): the same row-block
+// kernel with a PATTERN-CODED column index (csr_rowblock_coded_kernel, mgs_csr_optimize) — 8 B per entry streamed
+// instead of 12, same products in the same order; irregular row blocks keep their index slice.
 // No MFMA: arithmetic intensity is 0.13 flop/B; the bound is HBM (≈8 TB/s peak).
 #include "mgs_internal.hpp"
 
