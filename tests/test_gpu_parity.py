@@ -420,6 +420,17 @@ def test_properties_full_size_512(ctx, mg):
         ctx.set_option("fuse", 1)
     mg.lib().mgs_axpby(-1.0, Bu.h, 1.0, Bu0.h)
     assert Bu0.nrm2() <= 1e-12 * Bu.nrm2()
+    # pattern-coded index vs the plain CSR kernels at full size: the same bits, kernel and cycle
+    assert A.rowcode_info()["coded_blocks"] == A.rowcode_info()["blocks"] == n // 256
+    ctx.set_option("rowcode", 0)
+    try:
+        Bu0 = h.vcycle(u); y0 = A.spmv(u)
+    finally:
+        ctx.set_option("rowcode", 1)
+    y1 = A.spmv(u)
+    mg.lib().mgs_axpby(-1.0, Bu.h, 1.0, Bu0.h); mg.lib().mgs_axpby(-1.0, y1.h, 1.0, y0.h)
+    assert Bu0.nrm2() == 0.0 and y0.nrm2() == 0.0
+    del y0, y1
     # 30 preconditioned BiCGSTAB iterations: the recurrence residual it reports is the true residual
     x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, u, h, 30, 1e-12)
     assert st == 1 and it == 30 and tol < 0.2, (st, it, tol)          # status 1 = max_iter (bicg.cpp:134-135)
