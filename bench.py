@@ -230,13 +230,7 @@ def emit_json(obj):
         sys.stdout.write(line.decode()); sys.stdout.flush()
 
 
-def main():
-    # Libraries print banners on fd 1 (RCCL: "RCCL version : ...", Gloo: "[Gloo] Rank ..."); keep stdout
-    # clean for the one JSON line by pointing fd 1 at stderr for everything else.
-    global _REAL_STDOUT
-    sys.stdout.flush()
-    _REAL_STDOUT = os.dup(1)
-    os.dup2(2, 1)
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -252,7 +246,27 @@ def main():
     ap.add_argument("--cpu-grid", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    # ---- launch: N > 1 ranks are CHILD processes of a supervisor that never touches the GPU (multigridsolver_amd/launch.py)
+    if os.environ.get("MGS_BENCH_WORKER") != "1":
+        from multigridsolver_amd import launch
+        world_env = int(os.environ.get("WORLD_SIZE", "1"))
+        if world_env > 1:                                   # under torch.distributed.run: one supervisor per rank slot
+            if args.gpus != world_env:
+                raise SystemExit(f"--gpus {args.gpus} but the launcher started {world_env} ranks")
+            sys.exit(launch.supervise_rank(sys.argv, log))
+        if args.gpus > 1:                                   # plain `python bench.py --gpus N`: start the ranks ourselves
+            sys.exit(launch.spawn_ranks(sys.argv, args.gpus, log))
+    # Libraries print banners on fd 1 (RCCL: "RCCL version : ...", Gloo: "[Gloo] Rank ..."); keep stdout
+    # clean for the one JSON line by pointing fd 1 at stderr for everything else.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import multigridsolver_amd as mg
@@ -261,14 +275,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(0 if os.environ.get("MGS_DIST_SHARE_GPU") else local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if world > 1 or os.environ.get("MGS_FORCE_SHARDED"):   # MGS_FORCE_SHARDED: rehearse the sharded code path on one rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29755")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from multigridsolver_amd import dist as mgdist
-        return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json)
+        return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json,
+                                    cpu_baseline=None if args.no_cpu else (lambda: cpu_baseline(mg, args)),
+                                    pmc_traffic=pmc_traffic)
+    torch.cuda.set_device(local_rank)
 
     ctx = mg.Context(local_rank)
     N = args.grid

@@ -96,7 +96,9 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "valcode") ctx->opt_valcode = value;
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
+  else if (k == "native_graph") ctx->opt_native_graph = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
+  ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;
 }
 int mgs_ctx_set_native_allreduce(mgs_ctx *ctx, mgs_comm *c) { ctx->ncomm = c; return MGS_OK; }
@@ -551,6 +553,12 @@ int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]) {
   return MGS_OK;
 }
 
+int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]) {
+  int n = 0; for (auto &g : h->graphs) n += g.exec != nullptr;
+  out[0] = n; out[1] = (h->native || h->ntail) ? 1 : 0; out[2] = h->native_graph_failed ? 1 : 0; out[3] = h->native_eager_runs;
+  return MGS_OK;
+}
+
 int64_t mgs_hier_vcycle_bytes(const mgs_hier *h) {
   // algorithmic bytes of the kernels one zero-guess cycle actually launches.
   // Every level starts from x = 0: the first pre-sweep is the 24n-byte (ωD⁻¹)b kernel, not a
@@ -661,7 +669,8 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(T->send, b, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
       MGS_TRY(mgs_comm_allgather(T->comm, T->send, T->all, (size_t)std::max(T->maxn, 1)));
       MGS_TRY(k_gather(ctx, T->all, T->gidx, T->n_t, T->b->d));
-      MGS_TRY(mgs_vcycle(T->tail, T->b, T->x, 1));
+      if (h->capturing) MGS_TRY(cycle_level(T->tail, 0, T->b->d, T->x->d, true));   // part of the outer graph (prepare_fused ran before the capture)
+      else MGS_TRY(mgs_vcycle(T->tail, T->b, T->x, 1));
       if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(x, T->x->d + T->my_off, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
       return MGS_OK;
     }
@@ -837,10 +846,20 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;
   if (staged) { xw = L0.x->d; if (!zero_guess) MGS_HIP(ctx, hipMemcpyAsync(xw, x->d, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream)); }
-  const bool use_graph = ctx->opt_graph && !h->halo && !h->halo_begin && !h->coarse && !h->native && !h->ntail;
-  const int gkey = ctx->opt_fuse * 8 + ctx->opt_fuse_operands * 4 + ctx->opt_rowcode * 2 + ctx->opt_nt_store;
-  if (h->graph_fuse != gkey) drop_graph(h);
-  h->graph_fuse = gkey;
+  // Native transport (RCCL send/recv groups and the tail all-gather are enqueued on this stream by the cycle itself):
+  // capturable like any kernel launch once RCCL has set up its connections — two eager cycles first.
+  const bool native = h->native || h->ntail;
+  bool native_ok = false;
+  if (native && ctx->opt_native_graph && !h->native_graph_failed) {
+    // every exchange of the cycle must be native (installed callbacks are then never reached): each level with halo
+    // columns has a plan, and the coarsest level is either square or handed to the native tail
+    native_ok = h->ntail ? mgs_comm_capturable(h->ntail->comm) : (!h->coarse && h->lev.back().A->rows == h->lev.back().A->cols);
+    for (auto &q : h->lev) if (q.nx ? !mgs_comm_capturable(q.nx->comm) : q.A->cols > q.A->rows) native_ok = false;
+    if (native_ok && h->native_eager_runs < 2) { ++h->native_eager_runs; native_ok = false; }
+  }
+  const bool use_graph = ctx->opt_graph && (native ? native_ok : (!h->halo && !h->halo_begin && !h->coarse));
+  if (h->graph_epoch != ctx->opt_epoch) drop_graph(h);
+  h->graph_epoch = ctx->opt_epoch;
   if (!use_graph) {
     MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
   } else {
@@ -853,15 +872,28 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
     }
     if (!slot) {
       if (victim->exec) { hipGraphExecDestroy(victim->exec); *victim = mgs_hier::GraphSlot(); }
+      if (h->ntail) MGS_TRY(prepare_fused(h->ntail->tail));      // allocations of the tail happen outside the capture
       hipGraph_t g = nullptr;
       MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      h->capturing = true;
       int rc = cycle_level(h, 0, b->d, xw, zg != 0);
+      h->capturing = false;
       hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-      if (rc != MGS_OK) { if (g) hipGraphDestroy(g); return rc; }
-      if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-      e = hipGraphInstantiate(&victim->exec, g, nullptr, nullptr, 0);
-      hipGraphDestroy(g);
-      if (e != hipSuccess) { victim->exec = nullptr; return mgs_fail(ctx, MGS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+      if (e == hipSuccess && rc == MGS_OK) {
+        e = hipGraphInstantiate(&victim->exec, g, nullptr, nullptr, 0);
+        if (e != hipSuccess) victim->exec = nullptr;
+      }
+      if (g) hipGraphDestroy(g);
+      if (rc != MGS_OK || e != hipSuccess) {
+        if (!native) return rc != MGS_OK ? rc : mgs_fail(ctx, MGS_ERR_HIP, "cycle capture: %s", hipGetErrorString(e));
+        // the transport could not be captured on this platform: eager launches from here on (same arithmetic)
+        (void)hipGetLastError();
+        h->native_graph_failed = true;
+        ctx->err = std::string("native cycle not captured (") + (rc != MGS_OK ? ctx->err.c_str() : hipGetErrorString(e)) + "): eager launches";
+        MGS_TRY(cycle_level(h, 0, b->d, xw, zg != 0));
+        if (staged) MGS_HIP(ctx, hipMemcpyAsync(x->d, xw, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream));
+        return MGS_OK;
+      }
       victim->b = b->d; victim->x = xw; victim->zero = zg;
       slot = victim;
     }

@@ -37,6 +37,8 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
+  unsigned long long opt_epoch = 0;   // bumped by every mgs_ctx_set_option: captured cycles of an older epoch are dropped
   struct mgs_comm *ncomm = nullptr;   // native RCCL all-reduce of the inner products (takes precedence over the callback)
   mgs_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
@@ -100,6 +102,7 @@ struct mgs_comm;
 int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *recv, const int *rcnt);
 int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count);
 int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count);
+bool mgs_comm_capturable(const mgs_comm *c);   // false for the file-based stand-in of the tests (host-synchronous calls)
 // halo plan of one sharded level for the native exchange
 struct mgs_native_plan {
   mgs_comm *comm = nullptr;
@@ -165,7 +168,12 @@ struct mgs_hier {
   static constexpr int kGraphSlots = 4;
   GraphSlot graphs[kGraphSlots];
   unsigned long long graph_clock = 0;
-  int graph_fuse = -1;
+  unsigned long long graph_epoch = 0;   // ctx->opt_epoch the cached graphs were captured under
+  // native transport under capture: the first cycles run eagerly (RCCL sets up its peer connections lazily, which a
+  // capturing stream does not allow); a failed capture switches the hierarchy back to eager launches for good
+  int native_eager_runs = 0;
+  bool native_graph_failed = false;
+  bool capturing = false;
 };
 
 // ------------------------------------------------------------------ error plumbing

@@ -351,6 +351,8 @@ class ShardedHierarchy:
             env = os.environ.get("MGS_NATIVE_RCCL", "1")      # "force": also without the nccl backend (tests: MGS_LIBRCCL → stand-in)
             native = env == "force" or (comm.nccl and env != "0")
         self.native = bool(native) and self._enable_native(log)
+        # capture the native cycle (RCCL exchanges included) in a hipGraph: MGS_NATIVE_GRAPH=0 keeps eager launches
+        ctx.set_option("native_graph", 0 if os.environ.get("MGS_NATIVE_GRAPH", "1") == "0" else 1)
         return self
 
     # ---- native RCCL transport: the C++ cycle packs, exchanges (ncclSend/ncclRecv) and gathers the tail by itself
@@ -522,32 +524,38 @@ class ShardedHierarchy:
 
 
 # ------------------------------------------------------------------ bench leg for N > 1
-def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None):
-    """strong scaling: the args.grid^3 problem split by plane ranges over `world` GPUs"""
+def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None, cpu_baseline=None, pmc_traffic=None):
+    """strong scaling: the args.grid^3 problem split by plane ranges over `world` GPUs.  Runs as a rank worker of
+    multigridsolver_amd/launch.py (watchdog heartbeats, generation = which transport this attempt uses)."""
     import json
     import time
 
     import torch
     import torch.distributed as dist
 
-    from . import Context, OP_SPMV
+    from . import Context, OP_SPMV, launch
+    wd = launch.Watchdog() if os.environ.get("MGS_BENCH_WORKER") == "1" else None
+    beat = (lambda ph: wd.beat(ph)) if wd else (lambda ph: None)
+    beat("init_process_group")
     if not dist.is_initialized():
         # MGS_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); the
         # real multi-GPU run uses nccl (= RCCL over xGMI)
-        dist.init_process_group(backend=os.environ.get("MGS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
+        launch.init_process_group(os.environ.get("MGS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     if os.environ.get("MGS_DIST_SHARE_GPU"):
         local_rank = 0
-        torch.cuda.set_device(0)
+    torch.cuda.set_device(local_rank)
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = Context(local_rank, stream.cuda_stream)
     comm = Comm()
     N = args.grid
     lo, hi = plane_range(N, world, rank)
+    beat("operator")
     A = ctx.poisson3d(N, lo, hi, local_cols=True)
     n_loc, n_ext = A.shape
     t0 = time.perf_counter()
     sh = ShardedHierarchy(ctx, A, poisson_plane_plan(N, world, rank), args.omega, args.nu1, args.nu2, comm)
+    beat("hierarchy + transport")
     sh.build(args.ktg, args.npass, args.tou, coarse_rows=args.coarse_rows, log=log if rank == 0 else None)
     ctx.sync(); dist.barrier()
     t_setup = time.perf_counter() - t0
@@ -555,6 +563,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
     x = ctx.vec(n_ext)
     # local fine-level SpMV kernel rate (HIP events on the kernel's stream), and with the exchange
     xs = ctx.vec(n_ext).rand(seed=1, offset=lo * N * N); y = ctx.vec(n_loc)
+    beat("kernel timing")
     ctx.set_option("rowcode", 0)                      # plain CSR kernel beside the shipped pattern-coded one
     A.time_kernel(OP_SPMV, xs, out=y, reps=3)
     ms_k_csr = A.time_kernel(OP_SPMV, xs, out=y, reps=args.kernel_reps)
@@ -570,21 +579,38 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
         sh.spmv(xs, y)
     ctx.sync(); torch.cuda.synchronize()
     ms_x = (time.perf_counter() - t0) / args.kernel_reps * 1e3
-    for _ in range(args.warmup):
+    beat("warm-up cycles")
+    for _ in range(max(args.warmup, 3)):              # ≥ 3: the native cycle is captured in a hipGraph after two eager runs
         sh.vcycle(b, x)
     ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+    beat("timed cycles")
+    ex0 = sh.n_exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sh.vcycle(b, x)
     ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+    ex_per_cycle = (sh.n_exchanges - ex0) / max(args.steps, 1)
     el = np.array([time.perf_counter() - t0, ms_k, ms_x])
     comm.allreduce_host(el, op="max")
     elapsed, ms_k, ms_x = float(el[0]), float(el[1]), float(el[2])
+    beat("solve check")
     st, it, tol = sh.bicgstab(ctx.vec(n_ext), b, 300, 1e-10)
+    out = None
     if rank == 0:
         n, nnz = N ** 3, 7 * N ** 3 - 6 * N * N
         loc_bytes = spmv_bytes(n_loc, A.nnz)
         g = loc_bytes / (ms_k * 1e-3) / 1e9
+        code = A.rowcode_info()
+        streamed = (8 * A.nnz + 21 * n_loc + 4 * code["table_ints"] + 8 * (code["blocks"] + 1)) if code["coded_blocks"] == code["blocks"] else None
+        # HBM traffic of the shard's launch: the committed PMC measurement of the full-grid launch (same kernel, same bytes
+        # per row) scaled by this shard's share of the rows — counters cannot be read inside a multi-process run
+        tr = pmc_traffic("spmv", N) if pmc_traffic else None
+        traffic = tr[0] * n_loc / n if tr else None
+        ncomm = getattr(sh, "_ncomm", None)
+        cw, cr = C.c_int(-1), C.c_int(-1)
+        if ncomm is not None:
+            lib().mgs_comm_size(ncomm, C.byref(cw), C.byref(cr))
+        graph_info = sh.h.graph_info() if hasattr(sh.h, "graph_info") else None
         out = {"metric": "V-cycles/sec + fine-level SpMV HBM GB/s, 512³ 7-pt Poisson, 1/2/4/8 GPU",
                "value": args.steps / elapsed, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -593,19 +619,43 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                                       f"damped-Jacobi cycle, omega={args.omega}, device-built hierarchy ktg={args.ktg} npass={args.npass} tou={args.tou}",
                           "grid": N, "rows": n, "nnz": nnz, "parallelism": f"row-shard x{world} (" + ("native RCCL send/recv inside the C++ cycle" if sh.native else "torch.distributed all_to_all callbacks") + ", replicated coarse tail)",
                           "sharded_levels": len(sh.plans), "total_levels": sh.nlev, "setup_seconds": t_setup},
+               "transport": {"backend": dist.get_backend(), "world": world, "rank": rank, "native_rccl": bool(sh.native),
+                             "mgs_comm_size": [cw.value, cr.value] if ncomm is not None else None,
+                             "cycle_graph": graph_info, "generation": os.environ.get("MGS_BENCH_GEN_NAME"),
+                             "exchanges_per_cycle_callbacks": None if sh.native else ex_per_cycle},
                "spmv_hbm_gbps": spmv_bytes(n, nnz) / (ms_x * 1e-3) / 1e9,
-               "roofline": {"bound": "hbm", "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0, "traffic": None,
+               "roofline": {"bound": "hbm", "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0, "traffic": traffic,
+                            "traffic_source": (tr[1] + f" (full-grid launch, scaled by this shard's rows {n_loc}/{n})") if tr else None,
+                            "hbm_gbps": traffic / (ms_k * 1e-3) / 1e9 if traffic else None,
+                            "hbm_frac": traffic / (ms_k * 1e-3) / 1e9 / 8000.0 if traffic else None,
                             "kernel": "csr_rowblock_coded_kernel<SPMV> (rank 0 shard, per-GPU rate; CSR SpMV with pattern-coded column index)",
                             "algorithmic_bytes_per_launch": loc_bytes, "ms_per_launch": ms_k, "ms_spmv_with_halo_exchange": ms_x,
-                            "note": "achieved = SURVEY §8d-d3 CSR bytes of the shard / time; the coded kernel streams 8 B per entry + 1 B per row "
-                                    "instead of 12 B per entry (DESIGN.md §4); csr_kernel = plain 12 B/entry CSR kernel on the same shard",
+                            "streamed_bytes_per_launch": streamed, "streamed_gbps": streamed / (ms_k * 1e-3) / 1e9 if streamed else None,
+                            "note": "achieved/frac = SURVEY §8d-d3 CSR bytes of the shard (12·nnz + 20·n + 4) / time: an EFFECTIVE rate — the coded kernel "
+                                    "streams 8 B per entry + 1 B per row (DESIGN.md §4), so hbm_gbps/hbm_frac (PMC traffic / time) is the physical HBM "
+                                    "rate; csr_kernel = plain 12 B/entry CSR kernel on the same shard",
                             "csr_kernel": {"ms": ms_k_csr, "gbps": loc_bytes / (ms_k_csr * 1e-3) / 1e9},
                             "fused_pass_form": sh.h.fused_info(0)},
                "solve_check": {"bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol},
                "cpu_baseline": None}
-        (emit_json or (lambda o: print(json.dumps(o), flush=True)))(out)
+    beat("teardown")
     dist.barrier()
-    sh.close()
-    del sh, b, x, xs, y, A
-    ctx.close()
-    dist.destroy_process_group()
+    try:
+        sh.close()
+        del sh, b, x, xs, y, A
+        ctx.close()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        log("teardown:", repr(e))
+    if rank == 0:
+        # CPU baseline on rank 0's host cores, after the other ranks are done (they do not wait for it)
+        if cpu_baseline is not None:
+            beat("cpu baseline")
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                log("cpu_baseline failed:", repr(e))
+        (emit_json or (lambda o: print(json.dumps(o), flush=True)))(out)
+    launch.mark_done()
+    if wd:
+        wd.stop()

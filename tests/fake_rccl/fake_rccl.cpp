@@ -17,6 +17,9 @@
 #include <thread>
 #include <vector>
 
+// tells libmgs that these entry points are host-synchronous (never captured into a hipGraph)
+extern "C" int mgs_fake_rccl_marker = 1;
+
 struct ncclComm {
   std::string dir;
   int world = 0, rank = 0;

@@ -1,0 +1,58 @@
+"""The rank launcher of bench.py --gpus N (multigridsolver_amd/launch.py) on CPU: both ways in (plain `python script --gpus N`
+spawning its own ranks; per-rank supervisors under torch.distributed.run), the generation fallback after a failed or hung
+attempt, and the done-marker that keeps a teardown crash from restarting anything.  gloo, world 2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+DUMMY = os.path.join(REPO, "tests", "launch_dummy.py")
+
+
+def _run(cmd, extra_env=None, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("MGS_BENCH_WORKER", "MGS_BENCH_GEN", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MGS_NATIVE_RCCL", "MGS_NATIVE_GRAPH", "MGS_DIST_BACKEND"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=REPO)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (2, "exit"), (1, "hang"), (0, "crash_after_done")])
+def test_spawn_ranks_generations(ok_from, mode):
+    r, out = _run([sys.executable, DUMMY, str(ok_from), mode, "2"], {"MGS_BENCH_WATCHDOG_S": "4"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(out) == 1 and out[0]["generation"] == ok_from and out[0]["sum"] == 1.0 and out[0]["world"] == 2, out
+    if ok_from == 0:
+        assert out[0]["native"] == "1" and out[0]["graph"] == "1"
+    if ok_from == 2:
+        assert out[0]["native"] == "0"
+
+
+def test_spawn_ranks_gives_up_with_the_workers_code():
+    r, out = _run([sys.executable, DUMMY, "99", "exit", "2"])
+    assert r.returncode != 0 and out == []
+
+
+@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (1, "exit"), (1, "hang")])
+def test_supervisors_under_torchrun(ok_from, mode):
+    port = 29300 + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           DUMMY, str(ok_from), mode, "2"]
+    r, out = _run(cmd, {"MGS_BENCH_WATCHDOG_S": "4"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(out) == 1 and out[0]["generation"] == ok_from and out[0]["sum"] == 1.0, out
+
+
+def test_first_generation_honours_explicit_choices():
+    from multigridsolver_amd import launch
+    assert launch.first_generation({}) == 0
+    assert launch.first_generation({"MGS_NATIVE_GRAPH": "0"}) == 1
+    assert launch.first_generation({"MGS_NATIVE_RCCL": "0"}) == 2
+    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo"}) == 3
+    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo", "MGS_NATIVE_RCCL": "force"}) == 1

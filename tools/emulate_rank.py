@@ -56,7 +56,7 @@ for overlap, fused, native in configs:
     t_all = time.perf_counter() - t0
     print(f"native={int(sh.native)} overlap={int(overlap)} fused={int(fused)}: sharded levels {[p.n_loc for p in sh.plans]} (+tail {sh.tail.nlev} levels), setup {t_setup:.2f} s, "
           f"{t_all / reps * 1e3:.3f} ms per cycle (host enqueue {t_host / reps * 1e3:.3f} ms), {(sh.n_exchanges - ex0) / reps:.0f} exchanges per cycle; "
-          f"level-0 form {sh.h.fused_info(0)}", flush=True)
+          f"level-0 form {sh.h.fused_info(0)}; graph {sh.h.graph_info()}", flush=True)
     sh.close()
     del sh, b, x
 # the same slab as an unsharded-size reference: one GPU's share of the work without any exchange
