@@ -310,7 +310,8 @@ int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]);
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]);
 /* hipGraph state of the cycle (diagnostics): out[0] captured cycles cached, out[1] = 1 on the native RCCL transport, out[2] = 1 if
  * capturing the native cycle failed (eager launches since), out[3] eager native cycles run before the first capture.
- * Option "native_graph" (default 1): capture the row-sharded cycle including its RCCL exchanges (two eager cycles first). */
+ * Option "native_graph" (default 1): capture the row-sharded cycle including its RCCL exchanges (two eager cycles first).
+ * Option "native_overlap" (default 0): inside that graph, interior row blocks of the big levels on a second stream beside the exchange. */
 int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements (initial values of every context: environment MGS_OPTIONS="key=value,...").  key: "spmv_variant", "xcd_remap", "nontemporal",

@@ -29,6 +29,40 @@ static int native_exchange(mgs_hier *h, int l, int kind, const void *pa, const v
   return MGS_OK;
 }
 
+// Overlapped exchange inside a captured cycle.  The RCCL calls stay on the stream the capture began on: RCCL forks to
+// streams of its own inside a capture, and this HIP runtime only survives that on the ORIGIN stream (a forked stream that
+// forks again ends in a cycle of the capture bookkeeping — hipStreamEndCapture recursed until the stack ran out).  What
+// moves to the context's second stream is the kernel over the interior row blocks, which needs no halo value:
+//   origin:  producer → [fork] → pack → RCCL group → [join] → boundary row blocks → …
+//   second:             interior row blocks ──────────┘
+// Under capture the two cross-stream dependencies are edges of the graph.
+static int fork_side(mgs_hier *h, hipEvent_t *join) {
+  mgs_ctx *ctx = h->ctx;
+  while (h->fork_events.size() < h->fork_used + 2) {
+    hipEvent_t e; MGS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->fork_events.push_back(e);
+  }
+  hipEvent_t fork = h->fork_events[h->fork_used++]; *join = h->fork_events[h->fork_used++];
+  MGS_HIP(ctx, hipEventRecord(fork, ctx->stream));
+  MGS_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, fork, 0));
+  return MGS_OK;
+}
+// runs `interior` (kernel launches on ctx->stream) on the second stream, then the exchange on the origin, then joins
+template <class F>
+static int overlapped_exchange(mgs_hier *h, int l, int kind, const void *pa, const void *pb, double *out, F interior) {
+  mgs_ctx *ctx = h->ctx;
+  hipEvent_t join;
+  MGS_TRY(fork_side(h, &join));
+  hipStream_t origin = ctx->stream;
+  ctx->stream = ctx->comm_stream;
+  int rc = interior();
+  ctx->stream = origin;
+  MGS_TRY(rc);
+  MGS_HIP(ctx, hipEventRecord(join, ctx->comm_stream));
+  MGS_TRY(native_exchange(h, l, kind, pa, pb, out));
+  MGS_HIP(ctx, hipStreamWaitEvent(ctx->stream, join, 0));
+  return MGS_OK;
+}
+
 extern "C" {
 
 const char *mgs_version(void) { return "multigridsolver_amd 0.1 (gfx950, f64)"; }
@@ -75,6 +109,7 @@ int mgs_ctx_destroy(mgs_ctx *c) {
   if (c->red_dev) hipFree(c->red_dev);
   if (c->red_host) hipHostFree(c->red_host);
   if (c->own_stream) hipStreamDestroy(c->stream);
+  if (c->comm_stream) hipStreamDestroy(c->comm_stream);
   delete c;
   return MGS_OK;
 }
@@ -97,6 +132,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else if (k == "native_graph") ctx->opt_native_graph = value;
+  else if (k == "native_overlap") ctx->opt_native_overlap = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;
@@ -375,6 +411,7 @@ int mgs_hier_destroy(mgs_hier *h) {
   if (!h) return MGS_OK;
   hipStreamSynchronize(h->ctx->stream);
   drop_graph(h);
+  for (hipEvent_t e : h->fork_events) hipEventDestroy(e);
   for (auto &L : h->lev) level_free(L);
   if (h->inv) hipFree(h->inv);
   free_native_tail(h);
@@ -607,7 +644,7 @@ static int halo_x(mgs_hier *h, int l, double *x) {
 // one SpMV-shaped kernel on level l with x's halo refreshed first; with split-phase callbacks the
 // interior row blocks run while the exchange is in flight
 static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out) {
-  if (h->lev[l].nx) {    // native RCCL exchange on this stream, then one launch
+  if (h->lev[l].nx) {    // native RCCL exchange, then one launch
     MGS_TRY(native_exchange(h, l, 2, x, nullptr, x + A->rows));
     return mgs_launch_csr_op(A, op, x, b, dinv, omega, out);
   }
@@ -706,6 +743,11 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     auto fused_pass = [&](int which, int kind, const void *pa, const void *pb, const double *bvec, const double *xin, const int *agg,
                           const double *ec, double *out, double *out2) -> int {
       if (!halo) return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, nullptr, 0, nb);
+      if (L.nx && h->capturing && split && ctx->comm_stream) {
+        MGS_TRY(overlapped_exchange(h, l, kind, pa, pb, L.hbuf->d, [&]() {
+          return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, lo, hi); }));
+        return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, lo + nb - hi, lo, hi - lo);
+      }
       if (L.nx) {
         MGS_TRY(native_exchange(h, l, kind, pa, pb, L.hbuf->d));
         return mgs_launch_fused_range(L.A, which, L.wd->d, bvec, xin, agg, ec, out, out2, hv, 0, nb);
@@ -729,7 +771,12 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
                           (!halo || (mgs_rowcode_usable(&Ahat, true) && mgs_rowcode_usable(&Amap, true)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
                           const double *dv, const double *xin, const int *agg, double *out, int isplit) -> int {
-      if (L.nx) {      // native RCCL exchange of the payload on this stream, then one launch
+      if (L.nx && h->capturing && split && ctx->comm_stream) {      // captured cycle: interior row blocks beside the exchange
+        MGS_TRY(overlapped_exchange(h, l, kind, pa, pb, L.hbuf->d, [&]() {
+          return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, lo, hi); }));
+        return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, lo + nb - hi, lo, hi - lo);
+      }
+      if (L.nx) {      // native RCCL exchange of the payload, then one launch
         MGS_TRY(native_exchange(h, l, kind, pa, pb, L.hbuf->d));
         return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, nb);
       }
@@ -873,6 +920,9 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
     if (!slot) {
       if (victim->exec) { hipGraphExecDestroy(victim->exec); *victim = mgs_hier::GraphSlot(); }
       if (h->ntail) MGS_TRY(prepare_fused(h->ntail->tail));      // allocations of the tail happen outside the capture
+      if (native && ctx->opt_native_overlap && !ctx->comm_stream) MGS_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+      if (!ctx->opt_native_overlap && ctx->comm_stream) { hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
+      h->fork_used = 0;
       hipGraph_t g = nullptr;
       MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       h->capturing = true;

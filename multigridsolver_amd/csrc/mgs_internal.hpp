@@ -38,6 +38,9 @@ struct mgs_ctx {
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
+  int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:
+                              // a graph with cross-stream edges costs 0.48 ms of host time per launch and 1.219 vs 1.155 ms per cycle — off by default)
+  hipStream_t comm_stream = nullptr;   // second stream of the captured native cycle (fork/join become graph edges)
   unsigned long long opt_epoch = 0;   // bumped by every mgs_ctx_set_option: captured cycles of an older epoch are dropped
   struct mgs_comm *ncomm = nullptr;   // native RCCL all-reduce of the inner products (takes precedence over the callback)
   mgs_allreduce_fn allreduce = nullptr;
@@ -174,6 +177,8 @@ struct mgs_hier {
   int native_eager_runs = 0;
   bool native_graph_failed = false;
   bool capturing = false;
+  std::vector<hipEvent_t> fork_events;   // fork/join events of the captured native cycle (two per overlapped exchange)
+  size_t fork_used = 0;
 };
 
 // ------------------------------------------------------------------ error plumbing

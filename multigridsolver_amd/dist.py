@@ -162,9 +162,27 @@ class Comm:
         self.nccl = dist.get_backend() == "nccl"
         self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         self.cdev = self.device if self.nccl else torch.device("cpu")
+        # Host-synchronous collectives (setup handshakes, scalar reductions, barriers) run on a stream of their own: torch
+        # executes a blocking collective on the CURRENT stream and keeps polling its completion event from a watchdog thread,
+        # and an event that lives on the context's stream cannot be queried while that stream captures the cycle's hipGraph.
+        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def host_ops(self):
+        import contextlib
+        return self.torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
+
+    def barrier(self):
+        with self.host_ops():
+            self.dist.barrier()
+            if self.side is not None:
+                self.side.synchronize()
 
     def exchange_lists(self, lists):
         """variable-size all-to-all of int64 numpy arrays (setup only)"""
+        with self.host_ops():
+            return self._exchange_lists(lists)
+
+    def _exchange_lists(self, lists):
         t, d = self.torch, self.dist
         cnt = t.tensor([len(a) for a in lists], dtype=t.int64, device=self.cdev)
         rcnt = t.empty_like(cnt)
@@ -180,17 +198,31 @@ class Comm:
 
     def allgather_ints(self, v):
         t, d = self.torch, self.dist
-        x = t.tensor([int(v)], dtype=t.int64, device=self.cdev)
-        out = t.empty(self.world, dtype=t.int64, device=self.cdev)
-        d.all_gather_into_tensor(out, x)
-        return out.cpu().numpy()
+        with self.host_ops():
+            x = t.tensor([int(v)], dtype=t.int64, device=self.cdev)
+            out = t.empty(self.world, dtype=t.int64, device=self.cdev)
+            d.all_gather_into_tensor(out, x)
+            return out.cpu().numpy()
 
     def allreduce_host(self, a, op="sum"):
         """in-place reduction of a float64 numpy array over ranks"""
         t, d = self.torch, self.dist
-        x = t.from_numpy(a).to(self.cdev)
-        d.all_reduce(x, op={"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN}[op])
-        a[:] = x.cpu().numpy()
+        with self.host_ops():
+            x = t.from_numpy(a).to(self.cdev)
+            d.all_reduce(x, op={"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN}[op])
+            a[:] = x.cpu().numpy()
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        with self.host_ops():
+            self.dist.all_gather_object(out, obj)
+        return out
+
+    def broadcast_object(self, obj, src=0):
+        box = [obj]
+        with self.host_ops():
+            self.dist.broadcast_object_list(box, src=src)
+        return box[0]
 
     def a2a_f64(self, recv, send, recv_counts, send_counts, async_op=False):
         """recv/send: 1-D float64 torch tensors on self.device.  async_op: returns a work handle
@@ -258,7 +290,7 @@ class ShardedHierarchy:
         plan.dev_send_idx = t.from_numpy(idx.astype(np.int32)).to(self.comm.device)
         self._bufs[level] = t.empty(max(len(idx), 1), dtype=t.float64, device=self.comm.device)
 
-    def _exchange(self, level, x_ptr, async_op=False):
+    def _exchange(self, level, x_ptr, async_op=False, sync_pack=False):
         """halo of x on `level`: pack kernel (gather of the owned rows peers need) on the context's
         stream, then one all_to_all straight into x's halo slots.  Everything per (level, pointer)
         is cached: the hot loop does two ctypes calls and one collective."""
@@ -276,6 +308,8 @@ class ShardedHierarchy:
             return None
         if ns:
             check(lib().mgs_halo_pack(self.ctx.h, xv.h, idx_p, ns, buf_p), self.ctx.h)
+        if sync_pack:          # the collective runs on another stream than the context's (setup cross-check)
+            self.ctx.sync()
         self.n_exchanges += 1
         return self.comm.a2a_f64(recv, send, rcnt, scnt, async_op=async_op)
 
@@ -381,9 +415,7 @@ class ShardedHierarchy:
             if log:
                 log("exchange transport: torch.distributed callbacks")
             return False
-        box = [idbuf.raw]
-        comm.dist.broadcast_object_list(box, src=0)            # rank 0's id
-        idbuf = C.create_string_buffer(box[0], 128)
+        idbuf = C.create_string_buffer(comm.broadcast_object(idbuf.raw, src=0), 128)            # rank 0's id
         def fail(stage, e=None):
             if log:
                 log(f"native RCCL transport: {stage} failed" + (f" ({e!r})" if e is not None else "") + " -> torch.distributed callbacks")
@@ -416,7 +448,9 @@ class ShardedHierarchy:
                 n_ext = plan.n_loc + plan.n_halo
                 xa = ctx.vec(n_ext).rand(seed=1234 + l, offset=comm.rank * 7919); xb = ctx.vec(n_ext)
                 check(lib().mgs_vec_copy(xa.h, xb.h), ctx.h)
-                self._exchange(l, xa.ptr)
+                ctx.sync()
+                with comm.host_ops():                      # the torch collective's events stay off the context's stream
+                    self._exchange(l, xa.ptr, sync_pack=True); t.cuda.current_stream().synchronize()
                 check(lib().mgs_hier_native_halo(self.h.h, l, C.c_void_p(xb.ptr)), ctx.h)
                 ctx.sync(); t.cuda.synchronize()
                 same = bool(np.array_equal(xa.numpy(), xb.numpy()))
@@ -426,6 +460,8 @@ class ShardedHierarchy:
                 return fail(f"cross-check of the level-{l} exchange", locals().get("err"))
         if log:
             log("exchange transport: native RCCL inside the C++ cycle (verified against torch.distributed)")
+        # torch's collective watchdog retires finished work every 100 ms: let it finish before the first cycle is captured
+        t.cuda.synchronize(); import time; time.sleep(0.35)
         return True
 
     def _drop_native(self):
@@ -449,8 +485,7 @@ class ShardedHierarchy:
         offs = np.concatenate([[0], np.cumsum(nlocs)]).astype(np.int64)
         rp, ci, v = self.h.level_A(L).download()
         mine = shard_to_global(plan, rp, ci, v, offs, comm.rank)
-        parts = [None] * comm.world
-        comm.dist.all_gather_object(parts, (mine.indptr, mine.indices, mine.data))
+        parts = comm.all_gather_object((mine.indptr, mine.indices, mine.data))
         Ag = sps.vstack([sps.csr_matrix((d, i, p), shape=(len(p) - 1, int(offs[-1]))) for (p, i, d) in parts]).tocsr()
         Ag.sort_indices()
         n_t = Ag.shape[0]
@@ -557,7 +592,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
     sh = ShardedHierarchy(ctx, A, poisson_plane_plan(N, world, rank), args.omega, args.nu1, args.nu2, comm)
     beat("hierarchy + transport")
     sh.build(args.ktg, args.npass, args.tou, coarse_rows=args.coarse_rows, log=log if rank == 0 else None)
-    ctx.sync(); dist.barrier()
+    ctx.sync(); comm.barrier()
     t_setup = time.perf_counter() - t0
     b = ctx.vec(n_loc).rand(seed=0, offset=lo * N * N)
     x = ctx.vec(n_ext)
@@ -573,7 +608,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
     ms_k = A.time_kernel(OP_SPMV, xs, out=y, reps=args.kernel_reps)
     for _ in range(3):
         sh.spmv(xs, y)
-    ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+    ctx.sync(); torch.cuda.synchronize(); comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.kernel_reps):
         sh.spmv(xs, y)
@@ -582,13 +617,13 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
     beat("warm-up cycles")
     for _ in range(max(args.warmup, 3)):              # ≥ 3: the native cycle is captured in a hipGraph after two eager runs
         sh.vcycle(b, x)
-    ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+    ctx.sync(); torch.cuda.synchronize(); comm.barrier()
     beat("timed cycles")
     ex0 = sh.n_exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sh.vcycle(b, x)
-    ctx.sync(); torch.cuda.synchronize(); dist.barrier()
+    ctx.sync(); torch.cuda.synchronize(); comm.barrier()
     ex_per_cycle = (sh.n_exchanges - ex0) / max(args.steps, 1)
     el = np.array([time.perf_counter() - t0, ms_k, ms_x])
     comm.allreduce_host(el, op="max")
@@ -639,7 +674,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                "solve_check": {"bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol},
                "cpu_baseline": None}
     beat("teardown")
-    dist.barrier()
+    comm.barrier()
     try:
         sh.close()
         del sh, b, x, xs, y, A

@@ -37,8 +37,11 @@ for overlap, fused, native in configs:
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=2500, overlap=overlap, fused=fused, native=native, log=print)
     ctx.sync(); t_setup = time.perf_counter() - t0
     b = ctx.vec(n_loc).rand(seed=0); x = ctx.vec(A.shape[1])
-    for _ in range(5):
+    time.sleep(float(os.environ.get("EMU_SLEEP", "0")))     # lets torch's collective watchdog retire the setup collectives first
+    for i in range(5):
         sh.vcycle(b, x)
+        if os.environ.get("EMU_VERBOSE"):
+            ctx.sync(); print("  cycle", i, sh.h.graph_info(), mg.lib().mgs_last_error(ctx.h), flush=True)
     ctx.sync(); torch.cuda.synchronize()
     xn = x.numpy(n_loc)
     if fused:
