@@ -11,6 +11,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLD = os.path.join(REPO, "tests", "golden")
 INP = os.path.join(GOLD, "inputs")
+# the reference's bundled operators besides CSky3d30 (= config C3): golden vectors in tests/golden/bundled_<name>.npz,
+# P = the reference CPU AGMG "10 2 8" (results.txt:22-24), which the oracle's restatement reproduces exactly
+BUNDLED = ["CSky2d3", "CSky2d10", "CSky2d20", "CSky2d100", "CSky3d3", "CSky3d10", "CSky3d20"]
 
 
 def pytest_configure(config):
@@ -50,10 +53,12 @@ def inputs(tmp_path_factory, orc):
     for fn in os.listdir(INP):
         if fn.endswith(".mtx"):
             out[fn[:-4]] = os.path.join(INP, fn)
-    p = os.path.join(str(d), "CSky3d30.mtx")
-    with gzip.open(os.path.join(INP, "CSky3d30.mtx.gz"), "rb") as f, open(p, "wb") as g:
-        shutil.copyfileobj(f, g)
-    out["CSky3d30"] = p
+    for fn in os.listdir(INP):                     # the larger reference data files are committed gzipped
+        if fn.endswith(".mtx.gz"):
+            p = os.path.join(str(d), fn[:-3])
+            with gzip.open(os.path.join(INP, fn), "rb") as f, open(p, "wb") as g:
+                shutil.copyfileobj(f, g)
+            out[fn[:-7]] = p
     # poisson10000.mtx is not bundled by the reference: regenerate it with the
     # oracle's restatement of src/common/poisson.cpp and write it in that program's format.
     p = os.path.join(str(d), "poisson10000.mtx")

@@ -91,6 +91,48 @@ def test_primitives_vs_reference_golden(ctx, mg, orc, inputs, golden, case, Anam
         assert np.linalg.norm(Ao.residual(xn, b_np)) / np.linalg.norm(b_np) <= 1e-10 * 1.5
 
 
+from conftest import BUNDLED  # noqa: E402
+
+
+@pytest.mark.parametrize("name", BUNDLED)
+def test_bundled_operators_vs_reference_golden(ctx, mg, orc, inputs, golden, name):
+    """the HIP path on every bundled operator of the reference (P = reference CPU AGMG 10 2 8, rebuilt by the pinned
+    restatement and checked against the reference's groups): products bit-exact, Galerkin pattern-exact, two-grid cycle
+    ≤1e-10 vs the Eigen/SparseLU harness, BiCGSTABiml to 1e-10 with x ≤1e-8 from the reference's x; then the
+    device-built multilevel hierarchy solves the same system to 1e-10 (north_star bar)."""
+    g = golden("bundled_" + name)
+    Ao = orc.Csr.read(inputs[name]); Po = Ao.agmg(10.0, 2, 8.0)
+    grp = np.full(Po.shape[0], -1, dtype=np.int32); has = Po.rowptr[1:] > Po.rowptr[:-1]; grp[has] = Po.col[Po.rowptr[:-1][has]]
+    assert np.array_equal(grp, g["groups"])
+    A = mg.Csr.from_mtx(ctx, inputs[name]); P = dev(ctx, Po)
+    n = A.shape[0]
+    b_np = orc.rand_rhs(n); b = ctx.vec(b_np)
+    assert np.array_equal(A.spmv(b).numpy(), g["A_b"])
+    T = mg.Xfer.from_csr(P)
+    assert T.is_aggregation and np.array_equal(T.agg(), g["groups"])
+    rc = T.restrict(b)
+    assert np.array_equal(rc.numpy(), g["Pt_b"]) and np.array_equal(T.prolong(rc).numpy(), g["P_Pt_b"])
+    rp, ci, v = A.galerkin(T).download()
+    assert np.array_equal(rp, g["Ac_rowptr"]) and np.array_equal(ci, g["Ac_col"]) and rel(v, g["Ac_val"]) <= 1e-14
+    h = mg.Hierarchy(A, 0.5, 0, 0).push_P(P).finalize()
+    assert rel(h.vcycle(b).numpy(), g["mg_solve_b"]) <= 1e-10
+    for w, tag in [(0.5, "w05"), (0.8, "w08")]:
+        h.set_smoother(w, 0, 1)
+        assert rel(h.vcycle(b).numpy(), g[f"jac2grid_{tag}_b"]) <= 1e-10
+        xs = ctx.vec(n)
+        st, it, tol = mg.bicgstab(A, xs, b, h, 10000, 1e-10)
+        rst, rit = g[f"bicg_jac_{tag}_status_iters"]
+        assert st == 0 and abs(it - rit) <= max(2, rit // 6), (it, rit)
+        xn = xs.numpy()
+        assert rel(xn, g[f"x_bicg_jac_{tag}"]) <= 1e-8
+        assert np.linalg.norm(Ao.residual(xn, b_np)) / np.linalg.norm(b_np) <= 1.5e-10
+    # hierarchy aggregated on the device (config C3's form) on the same operator
+    hd = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 100, 32).finalize()
+    xs = ctx.vec(n)
+    st, it, tol = mg.bicgstab(A, xs, b, hd, 10000, 1e-10)
+    assert st == 0 and np.linalg.norm(Ao.residual(xs.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10, (st, it, tol)
+
+
 def test_vcycle_multilevel_vs_oracle(ctx, mg, orc, inputs):
     """3-level V(1,1)/V(2,1) cycle with reference-built P's, GPU vs CPU restatement."""
     Ao = orc.Csr.read(inputs["CSky3d30"]); P0o = orc.Csr.read(inputs["CSky3d30promatrix_cpu"])
