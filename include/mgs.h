@@ -308,6 +308,10 @@ int mgs_csr_optimize(mgs_csr *A);
  * array, of its halo-tagged copy (row shards) and of the aggregate-mapped array. */
 int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]);
 int mgs_csr_rowcode_info(const mgs_csr *A, int64_t out[4]);
+/* grouped pre pass of level `level` (filled in by the first cycle; option "fuse_restrict", default 1): out[0] row-block groups (0: the
+ * level runs the separate pre pass + restriction kernels), out[1] groups made of two row blocks, out[2] stray aggregates (restricted by
+ * the trailing kernel), out[3] row blocks. */
+int mgs_hier_group_info(const mgs_hier *h, int level, int64_t out[4]);
 /* hipGraph state of the cycle (diagnostics): out[0] captured cycles cached, out[1] = 1 on the native RCCL transport, out[2] = 1 if
  * capturing the native cycle failed (eager launches since), out[3] eager native cycles run before the first capture.
  * Option "native_graph" (default 1): capture the row-sharded cycle including its RCCL exchanges (two eager cycles first).

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "mgs_hier_fused_info": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "mgs_csr_rowcode_info": (C.c_int, [C.c_void_p, c_i64_p]),
     "mgs_hier_graph_info": (C.c_int, [C.c_void_p, c_i64_p]),
+    "mgs_hier_group_info": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "mgs_csr_destroy": (C.c_int, [C.c_void_p]),
     "mgs_csr_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mgs_csr_poisson3d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

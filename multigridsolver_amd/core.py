@@ -327,6 +327,10 @@ class Hierarchy:
         out = (C.c_int64 * 6)(); check(lib().mgs_hier_fused_info(self.h, level, out), self.ctx.h)
         return dict(zip(["blocks", "has_val_wd", "has_col_agg", "coded_col", "coded_col_halo", "coded_col_agg"], [int(v) for v in out]))
 
+    def group_info(self, level):
+        out = (C.c_int64 * 4)(); check(lib().mgs_hier_group_info(self.h, level, out), self.ctx.h)
+        return dict(zip(["groups", "paired_groups", "stray_aggregates", "blocks"], [int(v) for v in out]))
+
     def graph_info(self):
         out = (C.c_int64 * 4)(); check(lib().mgs_hier_graph_info(self.h, out), self.ctx.h)
         return dict(zip(["captured_cycles", "native_transport", "native_capture_failed", "native_eager_runs"], [int(v) for v in out]))

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
     bi = bvec[row]; wi = wd[row];
-    if (OP == FUSE_POST || OP == FUSE_POST_MAPPED) { xi = wi * xin[row]; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }   // x1 = wd∘b recomputed (xin = b)
+    if (OP == FUSE_POST || OP == FUSE_POST_MAPPED) { xi = xin ? wi * xin[row] : 0.0; const int a = agg[row]; pei = a >= 0 ? ec[a] : 0.0; }   // x1 = wd∘b recomputed (xin = b; NULL: bvec holds t = b + r)
   }
   if (staged) {
     const int nch = (hi - start + 1) >> 1;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_fused_kernel(
     const double s = staged ? fused_row_sum<OP, true>(vals, cols, ga - start, ge - start, wd, bvec, agg, ec, n, hv)
                             : fused_row_sum<OP, false>(val, col, ga, ge, wd, bvec, agg, ec, n, hv);
     if (OP == FUSE_PRE) { out[row] = bi - s; if (out2) out2[row] = wi * bi; }
-    else out[row] = (xi + pei) + wi * (bi - s);
+    else out[row] = xin ? (xi + pei) + wi * (bi - s) : pei + wi * (bi - s);
   }
 }
 
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
     ga = rowptr[row]; ge = rowptr[row + 1];
     if (OP != MGS_OP_SPMV) bi = b[row];
     if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
-    if (POST) { di = dinv[row]; xi = di * xin[row]; base = agg[row]; pei = base >= 0 ? x[base] : 0.0; }
+    if (POST) { di = dinv[row]; xi = xin ? di * xin[row] : 0.0; base = agg[row]; pei = base >= 0 ? x[base] : 0.0; }   // xin = NULL: b holds t = b + r
   }
   double s = 0.0;
   if (staged) {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
     if (OP == MGS_OP_SPMV) v = s;
     else if (OP == MGS_OP_RESIDUAL) v = bi - s;
     else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
-    else v = (xi + pei) + di * (bi - s);
+    else v = xin ? (xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
     if (capi < 0) __builtin_nontemporal_store(v, out + row); else out[row] = v;   // capi < 0: streaming store (A/B option nt_store)
   }
 }
@@ -667,6 +667,204 @@ __global__ __launch_bounds__(RB) void csr_rowblock_pipe_kernel(
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Grouped pre pass (DESIGN.md §4 "restriction inside the pre pass").  The V(1,1) cycle from x = 0 needs r = b − Â·b only
+// for two things: its restriction r_c = Pᵀr and the post pass, which needs b + r.  Aggregates of the pairwise matching
+// are 2–4 rows that sit in one row block or in two (a row and its neighbour one grid line further), so setup pairs such
+// row blocks into GROUPS; one workgroup sweeps the blocks of a group with the coded row-block kernel's body, keeps the
+// ≤ 512 residuals in LDS, writes t = b + r and restricts every aggregate whose members all lie in the group — same
+// members, same ascending order as restrict_agg_kernel, so r_c has the same bits.  The r vector never travels through HBM
+// (−8 B per row written, −8 B read back by the restriction, −4 B of member index, −8 B in the post pass, which reads t
+// instead of r and b).  Aggregates that leave their group (odd shapes at domain boundaries) are "strays": their member rows
+// also store r (bit mask), and a small trailing kernel restricts them from memory.
+constexpr int GRP_MAX_MEMBERS = 6;     // 4 + 10 + 5·10 = 64 bits of the member code
+constexpr int GRP_BLOCKS = 4;          // row blocks per group (residual buffer: up to 4·256 doubles of LDS)
+constexpr int GRP_DESC = 32;           // ints per group descriptor (128 B: blocks, entry bounds lo/hi, aggregate ranges lo/hi)
+
+// setup 1: aggregate ids must ascend with their first member (they do for the device matching: ids = rank of the leader);
+// afirst[b] = first aggregate whose first member lies in row block >= b; votes: per row block up to GRP_SLOTS distinct
+// other blocks its aggregates reach, with counts (the host pairs every block with its most frequent partner)
+constexpr int GRP_SLOTS = 4;
+__global__ void grp_scan_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, int nblocks,
+                                int *__restrict__ vkey, int *__restrict__ vcnt, int *__restrict__ afirst, int *__restrict__ bad) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nc) return;
+  const int lo = cptr[a], hi = cptr[a + 1];
+  if (hi <= lo) { atomicOr(bad, 1); return; }
+  const int fm = members[lo], fb = fm / RB, lb = members[hi - 1] / RB;
+  int pb = -1;
+  if (a > 0) {
+    const int plo = cptr[a - 1];
+    if (lo <= plo) { atomicOr(bad, 1); return; }
+    const int pfm = members[plo];
+    if (pfm >= fm) { atomicOr(bad, 1); return; }
+    pb = pfm / RB;
+  }
+  for (int q = pb + 1; q <= fb; ++q) afirst[q] = a;
+  if (a == nc - 1) for (int q = fb + 1; q <= nblocks; ++q) afirst[q] = nc;
+  if (lb != fb)
+    for (int sl = 0; sl < GRP_SLOTS; ++sl) {
+      const int old = atomicCAS(&vkey[fb * GRP_SLOTS + sl], -1, lb);
+      if (old == -1 || old == lb) { atomicAdd(&vcnt[fb * GRP_SLOTS + sl], 1); break; }
+    }
+}
+// setup 2: member positions inside the group's residual buffer (q-th block of the group: q·256 .. q·256+255), or stray
+__global__ void grp_code_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ blk2grp,
+                                const int *__restrict__ gblk, unsigned long long *__restrict__ acode, unsigned *__restrict__ wmask,
+                                int *__restrict__ stray, int stray_cap, int *__restrict__ nstray) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nc) return;
+  const int lo = cptr[a], cnt = cptr[a + 1] - lo;
+  const int g = blk2grp[members[lo] / RB];
+  int gb[GRP_BLOCKS];
+#pragma unroll
+  for (int q = 0; q < GRP_BLOCKS; ++q) gb[q] = gblk[GRP_BLOCKS * g + q];
+  bool ok = cnt <= GRP_MAX_MEMBERS;
+  unsigned long long code = (unsigned long long)cnt;
+  int prev = 0, sh = 14;
+  for (int k = 0; ok && k < cnt; ++k) {
+    const int m = members[lo + k], blk = m / RB;
+    int pos = -1;
+#pragma unroll
+    for (int q = 0; q < GRP_BLOCKS; ++q) if (blk == gb[q]) pos = q * RB + m - blk * RB;
+    if (pos < 0) { ok = false; break; }
+    if (k == 0) code |= (unsigned long long)pos << 4;
+    else { const int d = pos - prev; if (d <= 0 || d >= 1024) { ok = false; break; } code |= (unsigned long long)d << sh; sh += 10; }
+    prev = pos;
+  }
+  if (ok) { acode[a] = code; return; }
+  acode[a] = 0ull;
+  const int q = atomicAdd(nstray, 1);
+  if (q < stray_cap) stray[q] = a;
+  for (int k = 0; k < cnt; ++k) { const int m = members[lo + k]; atomicOr(&wmask[m >> 5], 1u << (m & 31)); }
+}
+__global__ void restrict_stray_kernel(int ns, const int *__restrict__ stray, const int *__restrict__ cptr, const int *__restrict__ members,
+                                      const double *__restrict__ r, double *__restrict__ rc) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ns) return;
+  const int a = stray[q];
+  double s = 0.0;
+  for (int k = cptr[a], e = cptr[a + 1]; k < e; ++k) s += r[members[k]];
+  rc[a] = s;
+}
+
+// the grouped pass itself: body of csr_rowblock_coded_kernel<RESIDUAL> per row block (coded table, uncoded index slice, or the
+// unstaged walk — block-uniform choices), then the in-LDS restriction of the group's aggregates
+template <int U, bool HALO>
+__global__ __launch_bounds__(RB) void csr_group_pre_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
+    const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
+    const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
+    double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split) {
+  extern __shared__ double lds_raw[];
+  const int g = map_block(bm, blockIdx.x);
+  if (g < 0) return;
+  const int tid = threadIdx.x;
+  double *__restrict__ vals = lds_raw;                                    // capv + 2 doubles
+  int *__restrict__ ints = reinterpret_cast<int *>(lds_raw + capv + 2);   // capi ints: the block's table, or its index slice
+  double *__restrict__ rbuf = lds_raw + capv + 2 + (capi + 1) / 2;        // residuals of the group's row blocks
+  // group descriptor (one 128-byte record, no dependent loads behind it): blocks, their entry bounds, their aggregate ranges
+  const int4_t *__restrict__ gd = reinterpret_cast<const int4_t *>(gdesc + (size_t)GRP_DESC * g);
+  const int4_t gb = gd[0], glo = gd[1], ghi = gd[2], galo = gd[3], gahi = gd[4];
+#define GSEL(v, h) ((h) == 0 ? (v).x : ((h) == 1 ? (v).y : ((h) == 2 ? (v).z : (v).w)))
+  // member codes of this lane's first aggregate per block: in flight while the blocks are swept
+  unsigned long long code0[GRP_BLOCKS];
+#pragma unroll
+  for (int h = 0; h < GRP_BLOCKS; ++h) { const int a = GSEL(galo, h) + tid; code0[h] = (GSEL(gb, h) >= 0 && a < GSEL(gahi, h)) ? acode[a] : 0ull; }
+#pragma unroll
+  for (int h = 0; h < GRP_BLOCKS; ++h) {
+    const int blk = GSEL(gb, h);
+    if (blk < 0) break;                                                   // group-uniform
+    if (h) __syncthreads();                                               // the previous block's LDS slice is done with
+    const int r0 = blk * RB, r1 = min(r0 + RB, n);
+    const int lo = GSEL(glo, h), hi = GSEL(ghi, h);
+    const int t0 = tptr ? tptr[blk] : 0, tlen = tptr ? tptr[blk + 1] - t0 : 0;
+    const int row = r0 + tid, start = lo & ~1, nent = hi - start;
+    const bool coded = tlen > 0 && tlen <= capi;
+    const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi);   // block-uniform
+    int ga = 0, ge = 0;
+    double bi = 0.0;
+    unsigned wm = 0u;
+    if (row < r1) { ga = rowptr[row]; ge = rowptr[row + 1]; bi = b[row]; wm = wmask[row >> 5]; }
+    double s = 0.0;
+    if (staged) {
+      const int nch = (nent + 1) >> 1;
+      if (coded) {
+#pragma unroll 4
+        for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+        for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
+      } else {
+#pragma unroll 4
+        for (int c = tid; c < nch; c += RB) {
+          const int k = start + 2 * c;
+          *reinterpret_cast<int2_t *>(ints + 2 * c) = *reinterpret_cast<const int2_t *>(idx + k);
+          *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
+        }
+      }
+      __syncthreads();
+      if (row < r1 && ge > ga) {
+        const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
+        if (coded) {
+          const int ps = ints[pid[row]];
+          const int last = my_e - my_a - 1;
+          for (int k = my_a, j = 0; k < my_e; k += U, j += U) {
+            int oq[U]; double xv[U], vq[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) oq[q] = ints[ps + min(j + q, last)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+              if (HALO && oq[q] >= CODE_HALO_LO) xv[q] = hv[row + (oq[q] - CODE_HALO)];
+              else xv[q] = x[row + oq[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+          }
+        } else {
+          for (int k = my_a; k < my_e; k += U) {
+            int cq[U]; double xv[U], vq[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) cq[q] = ints[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) xv[q] = (HALO && cq[q] >= split) ? hv[cq[q] - split] : x[cq[q]];
+#pragma unroll
+            for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+          }
+        }
+      }
+    } else if (row < r1) {
+      for (int k = ga; k < ge; ++k) { const int c = idx[k]; s += val[k] * ((HALO && c >= split) ? hv[c - split] : x[c]); }
+    }
+    if (row < r1) {
+      const double r = bi - s;
+      t_out[row] = bi + r;
+      rbuf[h * RB + tid] = r;
+      if ((wm >> (row & 31)) & 1u) r_out[row] = r;                        // member of a stray aggregate
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < GRP_BLOCKS; ++h) {
+    if (GSEL(gb, h) < 0) break;
+    const int a0 = GSEL(galo, h) + tid, ae = GSEL(gahi, h);
+    for (int a = a0; a < ae; a += RB) {
+      const unsigned long long code = a == a0 ? code0[h] : acode[a];
+      const int cnt = (int)(code & 15ull);
+      if (cnt == 0) continue;
+      int pos = (int)((code >> 4) & 1023ull), sh = 14;
+      double sum = 0.0;
+      sum += rbuf[pos];
+      for (int k = 1; k < cnt; ++k, sh += 10) { pos += (int)((code >> sh) & 1023ull); sum += rbuf[pos]; }
+      rc_out[a] = sum;
+    }
+  }
+#undef GSEL
 }
 
 // number of row blocks whose entry count exceeds each of 4 candidate LDS budgets
@@ -923,6 +1121,164 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 #undef CH_
 #undef C_
   MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+
+
+void mgs_free_groups(mgs_groups *g) {
+  if (!g) return;
+  if (g->gblk) hipFree(g->gblk); if (g->afirst) hipFree(g->afirst); if (g->acode) hipFree(g->acode); if (g->gdesc) hipFree(g->gdesc);
+  if (g->wmask) hipFree(g->wmask); if (g->stray) hipFree(g->stray);
+  delete g;
+}
+// Pairs the row blocks of A along its aggregates (see csr_group_pre_kernel).  *out stays NULL when the level does not
+// qualify: general P, aggregate ids not ascending with their first member, long rows, or more than opt_group_stray_pct % strays.
+int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_groups **out) {
+  *out = nullptr;
+  const int n = A->rows, nc = T ? T->n_coarse : 0;
+  if (!T || !T->aggregation || n <= 0 || nc <= 0 || A->max_row_len > 64 || !A->blkptr || A->lds_cap <= 0) return MGS_OK;
+  const int nblocks = (n + RB - 1) / RB;
+  hipStream_t st = ctx->stream;
+  mgs_groups *G = new mgs_groups();
+  G->nblocks = nblocks;
+  int *vkey = nullptr, *vcnt = nullptr, *flags = nullptr, *blk2grp = nullptr;
+  const size_t nv = (size_t)nblocks * GRP_SLOTS;
+  int rc = mgs_dev_alloc(ctx, &vkey, nv);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &vcnt, nv);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &flags, 2);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->afirst, (size_t)nblocks + 1);
+  std::vector<int> hk(nv), hn(nv), hg, hb2g((size_t)nblocks, -1);
+  int hflags[2] = {0, 0};
+  if (rc == MGS_OK) {
+    hipMemsetAsync(vkey, 0xff, sizeof(int) * nv, st);                  // −1: empty slot
+    hipMemsetAsync(vcnt, 0, sizeof(int) * nv, st);
+    hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+    hipLaunchKernelGGL(grp_scan_kernel, dim3((nc + RB - 1) / RB), dim3(RB), 0, st, nc, T->cptr, T->members, nblocks, vkey, vcnt, G->afirst, flags);
+    hipMemcpyAsync(hk.data(), vkey, sizeof(int) * nv, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(hn.data(), vcnt, sizeof(int) * nv, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping (scan) failed");
+  }
+  bool usable = rc == MGS_OK && hflags[0] == 0;
+  if (usable) {
+    // greedy union of row blocks along their most frequent links, groups of at most GRP_BLOCKS blocks (deterministic: links
+    // sorted by count, then by block pair)
+    struct Link { int cnt, a, b; };
+    std::vector<Link> links;
+    for (int b = 0; b < nblocks; ++b)
+      for (int sl = 0; sl < GRP_SLOTS; ++sl) {
+        const int k = hk[(size_t)b * GRP_SLOTS + sl], c = hn[(size_t)b * GRP_SLOTS + sl];
+        if (k > b && k < nblocks && c > 0) links.push_back({c, b, k});
+      }
+    std::sort(links.begin(), links.end(), [](const Link &p, const Link &q) { return p.cnt != q.cnt ? p.cnt > q.cnt : (p.a != q.a ? p.a < q.a : p.b < q.b); });
+    std::vector<int> parent((size_t)nblocks), gsize((size_t)nblocks, 1);
+    for (int b = 0; b < nblocks; ++b) parent[b] = b;
+    auto find = [&](int v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+    const int max_blocks = std::min(std::max(ctx->opt_group_blocks, 1), GRP_BLOCKS);
+    for (const Link &l : links) {
+      int ra = find(l.a), rb = find(l.b);
+      if (ra == rb || gsize[ra] + gsize[rb] > max_blocks) continue;
+      if (ra > rb) std::swap(ra, rb);
+      parent[rb] = ra; gsize[ra] += gsize[rb];                              // root = smallest block of the group
+    }
+    // groups in ascending order of their smallest block; blocks inside a group ascending
+    std::vector<int> gid((size_t)nblocks, -1);
+    int ng = 0;
+    for (int b = 0; b < nblocks; ++b) if (find(b) == b) gid[b] = ng++;
+    hg.assign((size_t)ng * GRP_BLOCKS, -1);
+    std::vector<int> fill((size_t)ng, 0);
+    for (int b = 0; b < nblocks; ++b) { const int g = gid[find(b)]; hb2g[b] = g; hg[(size_t)g * GRP_BLOCKS + fill[g]++] = b; }
+    G->ngroups = ng;
+    {   // distance, in groups, between a group and the one whose first block lies one far-band period further (middle of the matrix)
+      const int Db = (A->far_band + RB - 1) / RB, gm = ng / 2, fb = hg[(size_t)gm * GRP_BLOCKS];
+      int lo_g = gm, hi_g = ng;
+      while (lo_g < hi_g) { const int mid = (lo_g + hi_g) / 2; if (hg[(size_t)mid * GRP_BLOCKS] < fb + Db) lo_g = mid + 1; else hi_g = mid; }
+      G->plane_groups = lo_g - gm;
+    }
+    const int stray_cap = std::max((int)((int64_t)nc * std::min(std::max(ctx->opt_group_stray_pct, 0), 100) / 100), 1);
+    rc = mgs_dev_alloc(ctx, &G->gblk, hg.size());
+    if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &blk2grp, (size_t)nblocks);
+    if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->acode, (size_t)nc);
+    if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->wmask, (size_t)(n + 31) / 32 + 1);
+    if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->stray, (size_t)stray_cap);
+    if (rc == MGS_OK) {
+      hipMemcpyAsync(G->gblk, hg.data(), sizeof(int) * hg.size(), hipMemcpyHostToDevice, st);
+      hipMemcpyAsync(blk2grp, hb2g.data(), sizeof(int) * (size_t)nblocks, hipMemcpyHostToDevice, st);
+      hipMemsetAsync(G->wmask, 0, sizeof(unsigned) * ((size_t)(n + 31) / 32 + 1), st);
+      hipLaunchKernelGGL(grp_code_kernel, dim3((nc + RB - 1) / RB), dim3(RB), 0, st, nc, T->cptr, T->members, blk2grp, G->gblk, G->acode, G->wmask,
+                         G->stray, stray_cap, flags + 1);
+      hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, st);
+      if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping (codes) failed");
+    }
+    G->nstray = hflags[1];
+    usable = rc == MGS_OK && G->nstray <= stray_cap;
+    if (usable) {      // group descriptors: everything a workgroup needs about its blocks in one record
+      std::vector<int> hbp((size_t)nblocks + 1), haf((size_t)nblocks + 1), hd((size_t)ng * GRP_DESC, -1);
+      hipMemcpyAsync(hbp.data(), A->blkptr, sizeof(int) * ((size_t)nblocks + 1), hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(haf.data(), G->afirst, sizeof(int) * ((size_t)nblocks + 1), hipMemcpyDeviceToHost, st);
+      if (hipStreamSynchronize(st) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping (descriptors) failed");
+      int maxb = 1;
+      for (int g = 0; g < ng && rc == MGS_OK; ++g)
+        for (int q = 0; q < GRP_BLOCKS; ++q) {
+          const int b = hg[(size_t)g * GRP_BLOCKS + q];
+          int *d = &hd[(size_t)g * GRP_DESC];
+          d[q] = b; d[4 + q] = b >= 0 ? hbp[b] : 0; d[8 + q] = b >= 0 ? hbp[b + 1] : 0; d[12 + q] = b >= 0 ? haf[b] : 0; d[16 + q] = b >= 0 ? haf[b + 1] : 0;
+          if (b >= 0) maxb = std::max(maxb, q + 1);
+        }
+      G->max_blocks = maxb;
+      if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->gdesc, hd.size());
+      if (rc == MGS_OK && hipMemcpy(G->gdesc, hd.data(), sizeof(int) * hd.size(), hipMemcpyHostToDevice) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping: descriptor upload failed");
+      usable = rc == MGS_OK;
+    }
+  }
+  if (vkey) hipFree(vkey); if (vcnt) hipFree(vcnt); if (flags) hipFree(flags); if (blk2grp) hipFree(blk2grp);
+  if (getenv("MGS_DEBUG_GROUPS"))
+    fprintf(stderr, "[mgs groups] n=%d nc=%d blocks=%d: ids ascending=%d groups=%d strays=%d (limit %d%%) -> %s\n", n, nc, nblocks, hflags[0] == 0,
+            G->ngroups, G->nstray, ctx->opt_group_stray_pct, usable ? "grouped" : "separate kernels");
+  if (!usable) { mgs_free_groups(G); return rc; }
+  *out = G;
+  return MGS_OK;
+}
+
+int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *T, const double *x, const double *b,
+                         double *t_out, double *r_out, double *rc_out, const double *hv, int split) {
+  mgs_ctx *ctx = A->ctx;
+  if (A->rows == 0 || G->ngroups == 0) return MGS_OK;
+  const mgs_rowcode *c = (use_rowcode(A, A->code, hv != nullptr) && !A->code->vtab) ? A->code : nullptr;
+  const int capv = A->lds_cap;
+  const bool lean = c && (double)c->coded_blocks >= 0.985 * c->nblocks;
+  const int capi = lean ? std::max(c->tab_cap, 64) : std::max(c ? c->tab_cap : 0, capv + 2);
+  const size_t lds = (size_t)(capv + 2) * 8 + (size_t)((capi + 1) / 2) * 8 + (size_t)G->max_blocks * RB * 8 + 16 + (size_t)ctx->opt_lds_pad;
+  // workgroup → group map: XCD-contiguous, strip-major for far bands (distances in groups instead of row blocks)
+  BlockMap bm;
+  bm.base = 0; bm.nblocks = G->ngroups;
+  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
+  bm.chunk = (bm.nblocks + 7) / 8;
+  bm.D = 0; bm.S = 0; bm.P = 0;
+  int per_xcd = bm.chunk;
+  if (bm.remap && ctx->opt_strip != 0) {
+    const int Db = (A->far_band + RB - 1) / RB;
+    const int D = G->plane_groups;          // groups from one far-band period to the next (setup: first blocks Db apart)
+    if (Db >= 512 && D >= 64 && bm.chunk >= 2 * D) {
+      bm.D = D; bm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 32; bm.P = (bm.chunk + D - 1) / D;
+      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+    }
+  }
+  const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
+  const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
+#define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
+                                     c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
+                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
+#define GU_(UU) do { if (hv) G_(UU, true); else G_(UU, false); } while (0)
+  if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
+#undef GU_
+#undef G_
+  MGS_HIP(ctx, hipGetLastError());
+  if (G->nstray) {
+    hipLaunchKernelGGL(restrict_stray_kernel, dim3((G->nstray + RB - 1) / RB), dim3(RB), 0, ctx->stream, G->nstray, G->stray, T->cptr, T->members, r_out, rc_out);
+    MGS_HIP(ctx, hipGetLastError());
+  }
   return MGS_OK;
 }
 

@@ -131,6 +131,9 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "valcode") ctx->opt_valcode = value;
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
+  else if (k == "fuse_restrict") ctx->opt_fuse_restrict = value;
+  else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
+  else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "native_graph") ctx->opt_native_graph = value;
   else if (k == "native_overlap") ctx->opt_native_overlap = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
@@ -206,6 +209,7 @@ int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
   if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }
   if (A->blkptr) hipFree(A->blkptr);
+  if (A->origin) hipFree(A->origin);
   mgs_free_rowcode(A->code);
   delete A;
   return MGS_OK;
@@ -294,7 +298,7 @@ int mgs_jacobi(const mgs_csr *A, const mgs_vec *dinv, double omega, const mgs_ve
 int mgs_xfer_create(const mgs_csr *P, mgs_xfer **out) { return k_xfer_from_csr(P, out); }
 int mgs_xfer_destroy(mgs_xfer *T) {
   if (!T) return MGS_OK;
-  if (T->agg) hipFree(T->agg); if (T->cptr) hipFree(T->cptr); if (T->members) hipFree(T->members);
+  if (T->agg) hipFree(T->agg); if (T->cptr) hipFree(T->cptr); if (T->members) hipFree(T->members); if (T->corigin) hipFree(T->corigin);
   if (T->P) mgs_csr_destroy(T->P); if (T->Pt) mgs_csr_destroy(T->Pt);
   delete T;
   return MGS_OK;
@@ -377,6 +381,7 @@ static void level_free(mgs_level &L) {
   mgs_free_rowcode(L.code_agg);
   mgs_free_rowcode(L.code_pre);
   mgs_free_rowcode(L.code_hat);
+  mgs_free_groups(L.grp);
   if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
@@ -590,6 +595,12 @@ int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]) {
   return MGS_OK;
 }
 
+int mgs_hier_group_info(const mgs_hier *h, int level, int64_t out[4]) {
+  MGS_CHECK(h->ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_group_info: level %d out of range", level);
+  const mgs_groups *G = h->lev[level].grp;
+  out[0] = G ? G->ngroups : 0; out[1] = G ? G->nblocks - G->ngroups : 0;   /* blocks merged into another block's group */ out[2] = G ? G->nstray : 0; out[3] = (h->lev[level].A->rows + 255) / 256;
+  return MGS_OK;
+}
 int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]) {
   int n = 0; for (auto &g : h->graphs) n += g.exec != nullptr;
   out[0] = n; out[1] = (h->native || h->ntail) ? 1 : 0; out[2] = h->native_graph_failed ? 1 : 0; out[3] = h->native_eager_runs;
@@ -788,6 +799,14 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       if (!split) return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, nb);
       return mgs_launch_coded_range(V, op, xsrc, bvec, dv, 0.0, xin, agg, out, hv, isplit, 0, lo + nb - hi, lo, hi - lo);
     };
+    // Grouped form: pre pass + restriction in one kernel (r stays in LDS; L.r receives t = b + r, L.tmp the residuals of the
+    // few rows whose aggregate leaves its row-block group), post pass in its t-form.
+    const bool grouped = ctx->opt_fuse_restrict && operands && L.grp && !halo && !(Ahat.code && Ahat.code->vtab);
+    if (grouped) {
+      MGS_TRY(mgs_launch_group_pre(&Ahat, L.grp, L.T, b, b, L.r->d, L.tmp->d, C.b->d, nullptr, 0));
+      MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
+      return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, nullptr, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
+    }
     // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
     if (operands && halo) MGS_TRY(coded_pass(&Ahat, MGS_OP_RESIDUAL, 0, L.wd->d, b, b, b, nullptr, nullptr, nullptr, L.r->d, L.A->rows));
     else if (operands) MGS_TRY(mgs_launch_csr_op(&Ahat, MGS_OP_RESIDUAL, b, b, nullptr, 0.0, L.r->d));
@@ -866,6 +885,9 @@ static int prepare_fused(mgs_hier *h) {
         if (ctx->opt_rowcode)
           MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg,
                                     ctx->opt_valcode ? L.A->val : nullptr));
+      }
+      if (ctx->opt_fuse_restrict && !L.grp_tried && !shard) {   // row-block groups of the grouped pre pass (null: level does not qualify)
+        L.grp_tried = true; MGS_TRY(mgs_build_groups(ctx, L.A, L.T, &L.grp)); drop_graph(h);
       }
       // codes whose tuples depend on Â's values (or, on a shard, on the halo tags) follow val_wd
       if (ctx->opt_rowcode && new_vals && (shard || ctx->opt_valcode)) {

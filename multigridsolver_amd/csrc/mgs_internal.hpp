@@ -37,6 +37,9 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
+  int opt_group_blocks = 4;    // ... row blocks per group (1..4)
+  int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:
                               // a graph with cross-stream edges costs 0.48 ms of host time per launch and 1.219 vs 1.155 ms per cycle — off by default)
@@ -78,6 +81,8 @@ struct mgs_csr {
   int max_wave_nnz = 0;   // max entries of a 64-row group
   mgs_rowcode *code = nullptr;   // pattern code of col (mgs_csr_optimize; owned unless this is a view)
   bool code_tried = false;
+  int *origin = nullptr;   // coarse operators built by the device setup: the finest-level row each row descends from (its aggregate's
+                           // leader, chained through the levels) — the index space the matching's tie-breaks work in; NULL = identity
 };
 
 struct mgs_vec {
@@ -95,6 +100,7 @@ struct mgs_xfer {
   int *agg = nullptr;      // n_fine, -1 = not aggregated (G0)
   int *cptr = nullptr;     // n_coarse+1: member list offsets (Pᵀ rowptr)
   int *members = nullptr;  // nnz(P): fine rows sorted by aggregate (Pᵀ col)
+  int *corigin = nullptr;  // n_coarse: origin (see mgs_csr) of every aggregate, handed to the coarse operator
   int64_t nnz = 0;
   // general form
   mgs_csr *P = nullptr, *Pt = nullptr;
@@ -125,6 +131,20 @@ struct mgs_native_tail {
   mgs_vec *b = nullptr, *x = nullptr;
 };
 
+// Aggregate-complete row-block groups of a level (kernels_spmv.hip, "grouped pre pass"): one workgroup sweeps the 1–2 row
+// blocks of a group, keeps their residuals in LDS and restricts every aggregate that lies inside the group — the
+// restriction kernel and the residual vector's trip through HBM disappear.  Aggregates that leave their group
+// ("strays": odd shapes at domain boundaries) are restricted afterwards from the residuals their member rows also store.
+struct mgs_groups {
+  int ngroups = 0, nblocks = 0, nstray = 0, plane_groups = 0, max_blocks = 1;
+  int *gdesc = nullptr;                 // 32 ints per group: blocks[4], entry bounds lo[4]/hi[4], aggregate ranges lo[4]/hi[4]
+  int *gblk = nullptr;                  // 4 per group: its row blocks, ascending (−1: unused slot)
+  int *afirst = nullptr;                // nblocks+1: first aggregate whose first member lies in row block b (ids ascend with it)
+  unsigned long long *acode = nullptr;  // n_coarse: count | first position | position deltas (10 bits each) in the group's 1024-entry
+                                        // residual buffer; 0 = stray
+  unsigned *wmask = nullptr;            // (n+31)/32 bit mask: rows that also store r (members of stray aggregates)
+  int *stray = nullptr;                 // stray aggregate ids
+};
 struct mgs_level {
   const mgs_csr *A = nullptr;
   bool own_A = false;
@@ -139,6 +159,8 @@ struct mgs_level {
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
   mgs_rowcode *code_pre = nullptr;   // row shards: pattern code of col with tagged halo words (pre pass reads b + payload)
   mgs_rowcode *code_hat = nullptr;   // option valcode: pattern code of (col, val_wd) for the pre pass on Â
+  mgs_groups *grp = nullptr;         // aggregate-complete row-block groups (grouped pre pass = pre pass + restriction in one kernel)
+  bool grp_tried = false;
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
   double *kscal = nullptr;     // K-cycle scalars (device)
   double wd_omega = 0.0;       // ω that wd was built with
@@ -231,6 +253,12 @@ int mgs_launch_coded_range(const mgs_csr *A, int op, const double *x, const doub
                            const double *xin, const int *agg, double *out, const double *hv, int split, int blk_lo, int blk_hi,
                            int gap_at = 0x7fffffff, int gap_len = 0);
 void mgs_free_rowcode(mgs_rowcode *c);
+int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_groups **out);
+void mgs_free_groups(mgs_groups *g);
+// t = b + (b − Â·x) and r_c = Pᵀ(b − Â·x) in one pass over the groups of G; x = gather source (b itself, or with hv/split the
+// halo payload of a row shard); strays' member rows also store r into r_out, restricted by the trailing small kernel
+int mgs_launch_group_pre(const mgs_csr *Ahat, const mgs_groups *G, const mgs_xfer *T, const double *x, const double *b,
+                         double *t_out, double *r_out, double *rc_out, const double *hv, int split);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc);

@@ -266,6 +266,10 @@ __device__ __forceinline__ unsigned edge_hash(unsigned a, unsigned b) {
 // the edge whose lower end is an even multiple of the stride — on lexicographically numbered
 // grids this yields aligned pairs (2m,2m+1), i.e. the regular semi-coarsening the sequential
 // reference produces (AGMG.cpp:149-179 scans neighbours in ascending order) — then a hash.
+// i, j are ORIGIN indices: the finest-level row a node descends from (leader of its aggregate, chained through passes
+// and levels).  Node ids themselves drift against the grid wherever G0 rows or odd-sized aggregates were skipped in
+// the numbering, and the parity rule then flips in patches (round 1: 13–30 % of the aggregates misaligned against
+// their neighbours at 512³); in origin space the stride of a grid direction is exact on every level.
 __device__ __forceinline__ EdgeKey make_key(double w, int i, int j, int hash_only) {
   EdgeKey k; int mn = min(i, j), mx = max(i, j);
   k.w = hash_only ? 0.0 : w; k.d = hash_only ? 0 : mx - mn; k.par = hash_only ? 0 : ((mn / (mx - mn)) & 1);
@@ -280,17 +284,18 @@ __device__ __forceinline__ bool key_less(const EdgeKey &a, const EdgeKey &b) {
   return a.mn < b.mn;
 }
 __global__ void agg_pick_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ w,
-                                const int *__restrict__ state, int hash_only, int *__restrict__ pick) {
+                                const int *__restrict__ state, int hash_only, const int *__restrict__ origin, int *__restrict__ pick) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (state[i] != -1) { pick[i] = -3; return; }
   int best = -1; EdgeKey bk;
+  const int oi = origin ? origin[i] : i;
   for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
     double wk = w[k];
     if (!(wk < INFINITY)) continue;
     int j = col[k];
     if (state[j] != -1) continue;
-    EdgeKey key = make_key(wk, i, j, hash_only);
+    EdgeKey key = make_key(wk, oi, origin ? origin[j] : j, hash_only);
     if (best < 0 || key_less(key, bk)) { best = j; bk = key; }
   }
   pick[i] = best;
@@ -315,6 +320,13 @@ __global__ void agg_assign_kernel(int n, const int *__restrict__ state, const in
   if (i >= n) return;
   int st = state[i];
   agg[i] = st < 0 ? -1 : ids[min(i, st)];
+}
+// origin of every aggregate = smallest origin among its members (atomicMin: order-independent)
+__global__ void agg_origin_kernel(int n, const int *__restrict__ agg, const int *__restrict__ origin, int *__restrict__ corigin) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = agg[i];
+  if (a >= 0) atomicMin(&corigin[a], origin ? origin[i] : i);
 }
 __global__ void agg_compose_kernel(int n, int *__restrict__ agg, const int *__restrict__ agg2) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,7 +490,13 @@ int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_
   MGS_TRY(dalloc<int>(ctx, cm, (size_t)A->cols));
   const int n_halo = A->cols - A->rows;
   hipLaunchKernelGGL(colmap_ext_kernel, dim3(mgs_grid(A->cols, TB)), dim3(TB), 0, ctx->stream, A->rows, A->cols, T->n_coarse, T->agg, halo_map_dev, cm.as<int>());
-  return galerkin_core(A, T->n_coarse, T->cptr, T->members, cm.as<int>(), T->n_coarse + (halo_map_dev ? n_halo_c : n_halo), out);
+  MGS_TRY(galerkin_core(A, T->n_coarse, T->cptr, T->members, cm.as<int>(), T->n_coarse + (halo_map_dev ? n_halo_c : n_halo), out));
+  if (T->corigin && T->n_coarse > 0) {      // row shard: the coarse shard's rows keep their origins (local finest-level rows)
+    MGS_TRY(mgs_dev_alloc(ctx, &(*out)->origin, (size_t)T->n_coarse));
+    MGS_HIP(ctx, hipMemcpyAsync((*out)->origin, T->corigin, sizeof(int) * (size_t)T->n_coarse, hipMemcpyDeviceToDevice, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MGS_OK;
 }
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) { return k_galerkin_agg_ext(A, T, nullptr, 0, out); }
 
@@ -518,7 +536,7 @@ int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
 }
 
 // one pairwise pass on matrix M → agg ids (device array, caller frees) and count
-static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, int **agg_out, int *nc_out) {
+static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, const int *origin, int **agg_out, int *nc_out) {
   mgs_ctx *ctx = M->ctx;
   const int n = M->rows;
   DevBuf diag, s, state, w, pick, cnt, flag, asym;
@@ -544,7 +562,7 @@ static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, int **agg
     const int hash_only = round >= MU_ROUNDS;
     const int force = round == MAX_ROUNDS - 1;
     MGS_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(agg_pick_kernel, g, b, 0, st, n, M->rowptr, M->col, w.as<double>(), state.as<int>(), hash_only, pick.as<int>());
+    hipLaunchKernelGGL(agg_pick_kernel, g, b, 0, st, n, M->rowptr, M->col, w.as<double>(), state.as<int>(), hash_only, origin, pick.as<int>());
     hipLaunchKernelGGL(agg_match_kernel, g, b, 0, st, n, pick.as<int>(), state.as<int>(), force, cnt.as<int>());
     int left = 0;
     MGS_HIP(ctx, hipMemcpyAsync(&left, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -572,9 +590,17 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
   MGS_CHECK(ctx, ktg > 2.0 && npass >= 1, MGS_ERR_INVALID, "aggregate: need ktg > 2 and npass >= 1");
   const int n = A->rows;
   int *agg = nullptr; int nc = 0;
-  MGS_TRY(pairwise_pass(A, ktg, 1, &agg, &nc));
+  MGS_TRY(pairwise_pass(A, ktg, 1, A->origin, &agg, &nc));
   mgs_xfer *T = nullptr;
   MGS_TRY(xfer_from_agg(ctx, n, nc, agg, &T));
+  auto origin_of = [&](int nfine, const int *aggv, const int *org_fine, int ncoarse, int **out) -> int {
+    MGS_TRY(mgs_dev_alloc(ctx, out, (size_t)std::max(ncoarse, 1)));
+    MGS_HIP(ctx, hipMemsetAsync(*out, 0x7f, sizeof(int) * (size_t)std::max(ncoarse, 1), ctx->stream));
+    if (nfine) hipLaunchKernelGGL(agg_origin_kernel, dim3(mgs_grid(nfine, TB)), dim3(TB), 0, ctx->stream, nfine, aggv, org_fine, *out);
+    MGS_HIP(ctx, hipGetLastError());
+    return MGS_OK;
+  };
+  { int rc0 = origin_of(n, T->agg, A->origin, nc, &T->corigin); if (rc0 != MGS_OK) { mgs_xfer_destroy(T); return rc0; } }
   mgs_csr *Abar = nullptr;
   int rc = k_galerkin_agg(A, T, &Abar);
   if (rc != MGS_OK) { mgs_xfer_destroy(T); return rc; }
@@ -583,12 +609,15 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     if (Abar->rows <= 1) break;
     const int n_halo = A->cols - A->rows;                               // row shard: halo slots stay unaggregated here
     int *agg2 = nullptr; int nc2 = 0;
-    rc = pairwise_pass(Abar, ktg, 0, &agg2, &nc2);
+    rc = pairwise_pass(Abar, ktg, 0, T->corigin, &agg2, &nc2);
     if (rc != MGS_OK) break;
+    int *org2 = nullptr;
+    rc = origin_of(Abar->rows, agg2, T->corigin, nc2, &org2);
+    if (rc != MGS_OK) { hipFree(agg2); if (org2) hipFree(org2); break; }
     // compose fine→pair→pair-of-pairs (AGMG.cpp:247-263) and rebuild member lists
     int *aggc = nullptr;
     rc = mgs_dev_alloc(ctx, &aggc, (size_t)n);
-    if (rc != MGS_OK) { hipFree(agg2); break; }
+    if (rc != MGS_OK) { hipFree(agg2); hipFree(org2); break; }
     hipMemcpyAsync(aggc, T->agg, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
     hipLaunchKernelGGL(agg_compose_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, aggc, agg2);
     mgs_xfer *T2 = nullptr, *Tn = nullptr;
@@ -598,10 +627,17 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     if (rc == MGS_OK) rc = k_galerkin_agg(Abar, T2, &Anew);          // (P1 P2)ᵀ A (P1 P2) = P2ᵀ A_bar P2
     if (T2) mgs_xfer_destroy(T2);
     if (rc == MGS_OK) rc = xfer_from_agg(ctx, n, nc2, aggc, &Tn); else hipFree(aggc);
-    if (rc != MGS_OK) { if (Anew) mgs_csr_destroy(Anew); break; }
+    if (rc != MGS_OK) { if (Anew) mgs_csr_destroy(Anew); hipFree(org2); break; }
+    Tn->corigin = org2;
     mgs_xfer_destroy(T); T = Tn;
     mgs_csr_destroy(Abar); Abar = Anew;
   }
+  if (rc != MGS_OK) { mgs_xfer_destroy(T); mgs_csr_destroy(Abar); return rc; }
+  // the coarse operator inherits its rows' origins (tie-breaks of the next level's matching)
+  if (Abar->origin) { hipFree(Abar->origin); Abar->origin = nullptr; }
+  rc = mgs_dev_alloc(ctx, &Abar->origin, (size_t)std::max(T->n_coarse, 1));
+  if (rc == MGS_OK && hipMemcpyAsync(Abar->origin, T->corigin, sizeof(int) * (size_t)T->n_coarse, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "origin copy failed");
+  if (rc == MGS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "origin copy failed");
   if (rc != MGS_OK) { mgs_xfer_destroy(T); mgs_csr_destroy(Abar); return rc; }
   *T_out = T;
   if (A->rows == A->cols) *Ac_out = Abar;

@@ -146,6 +146,7 @@ def shard_to_global(plan, rowptr, col, val, offsets, rank):
     for p, ids in enumerate(plan.recv_ids):
         gmap[k:k + len(ids)] = offsets[p] + ids.astype(np.int64); k += len(ids)
     m = sps.csr_matrix((np.array(val, copy=True), gmap[col], np.array(rowptr, copy=True)), shape=(n_loc, int(offsets[-1])))
+    m.sum_duplicates()      # two halo slots name the same global row only in the one-GPU rehearsal (a slab exchanging with itself)
     m.sort_indices()
     return m
 

@@ -133,6 +133,41 @@ def test_bundled_operators_vs_reference_golden(ctx, mg, orc, inputs, golden, nam
     assert st == 0 and np.linalg.norm(Ao.residual(xs.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10, (st, it, tol)
 
 
+@pytest.mark.parametrize("kind", ["poisson3d_64", "poisson3d_40", "poisson3d_33", "poisson2d_130", "CSky3d30", "CSky2d100"])
+def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
+    """option fuse_restrict (default on): pre pass + restriction in one kernel over aggregate-complete row-block groups, post pass in its
+    t-form — against the separate kernels (≤1e-13: only the post pass's rounding differs) and against the oracle's cycle (≤1e-10)"""
+    if kind.startswith("poisson3d"):
+        A = ctx.poisson3d(int(kind.split("_")[1]))
+    elif kind.startswith("poisson2d"):
+        A = ctx.poisson2d(int(kind.split("_")[1]))
+    else:
+        A = mg.Csr.from_mtx(ctx, inputs[kind])
+    n = A.shape[0]
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
+    b = ctx.vec(n).rand(seed=3)
+    try:
+        ctx.set_option("group_stray_pct", 60)                # small grids: many aggregates leave their group — exercise that path too
+        ctx.set_option("fuse_restrict", 1); xg = h.vcycle(b).numpy()
+        info = [h.group_info(l) for l in range(h.nlev - 1)]
+        ctx.set_option("fuse_restrict", 0); xs = h.vcycle(b).numpy()
+    finally:
+        ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6)
+    assert info[0]["groups"] > 0, info                      # the device matching numbers aggregates by their leader: level 0 qualifies
+    assert rel(xg, xs) <= 1e-13, (rel(xg, xs), info)
+    # oracle cycle on the downloaded hierarchy
+    import scipy.sparse as sps
+    As, Ps = [], []
+    for l in range(h.nlev):
+        rp, ci, v = h.level_A(l).download(); r = h.level_shape(l)[0]
+        As.append(orc.Csr.from_arrays(r, r, rp, ci, v))
+        if l < h.nlev - 1:
+            T = h.level_P(l); a = T.agg(); nf, nc = T.shape; rows = np.nonzero(a >= 0)[0]
+            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(rows.size), (rows, a[rows])), shape=(nf, nc))))
+    ho = orc.Hier(As[0], Ps, omega=0.6, nu1=1, nu2=1, As=As)
+    assert rel(xg, ho.vcycle(b.numpy())) <= 1e-10
+
+
 def test_vcycle_multilevel_vs_oracle(ctx, mg, orc, inputs):
     """3-level V(1,1)/V(2,1) cycle with reference-built P's, GPU vs CPU restatement."""
     Ao = orc.Csr.read(inputs["CSky3d30"]); P0o = orc.Csr.read(inputs["CSky3d30promatrix_cpu"])

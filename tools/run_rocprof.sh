@@ -13,3 +13,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROO
 find $OUT -name "*.csv" | head -20
 # keep only compact files in gpurun_out (the trace CSV of 512^3 is small: few hundred dispatches)
 du -sh $OUT
+# the last ~150 dispatches (the final V-cycle) for tools/cycle_trace.py
+F=$(ls $OUT/trace/*/*_kernel_trace.csv | head -1); head -1 $F > $OUT/cycle_tail.csv; tail -150 $F >> $OUT/cycle_tail.csv
