@@ -1138,6 +1138,7 @@ int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_grou
   const int n = A->rows, nc = T ? T->n_coarse : 0;
   if (!T || !T->aggregation || n <= 0 || nc <= 0 || A->max_row_len > 64 || !A->blkptr || A->lds_cap <= 0) return MGS_OK;
   const int nblocks = (n + RB - 1) / RB;
+  if (nblocks < ctx->opt_group_min_blocks) return MGS_OK;      // small levels: too few workgroups once blocks are grouped
   hipStream_t st = ctx->stream;
   mgs_groups *G = new mgs_groups();
   G->nblocks = nblocks;

@@ -134,6 +134,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "fuse_restrict") ctx->opt_fuse_restrict = value;
   else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
+  else if (k == "group_min_blocks") ctx->opt_group_min_blocks = value;
   else if (k == "native_graph") ctx->opt_native_graph = value;
   else if (k == "native_overlap") ctx->opt_native_overlap = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
@@ -801,10 +802,22 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     };
     // Grouped form: pre pass + restriction in one kernel (r stays in LDS; L.r receives t = b + r, L.tmp the residuals of the
     // few rows whose aggregate leaves its row-block group), post pass in its t-form.
-    const bool grouped = ctx->opt_fuse_restrict && operands && L.grp && !halo && !(Ahat.code && Ahat.code->vtab);
+    // On a row shard the payload of the halo columns is exchanged first (no interior/boundary split in this form).
+    const bool grouped = ctx->opt_fuse_restrict && operands && L.grp && !(Ahat.code && Ahat.code->vtab) &&
+                         (!halo || L.nx || !split || (h->capturing));
     if (grouped) {
-      MGS_TRY(mgs_launch_group_pre(&Ahat, L.grp, L.T, b, b, L.r->d, L.tmp->d, C.b->d, nullptr, 0));
+      auto payload = [&](int kind, const void *pa, const void *pb) -> int {
+        if (!halo) return MGS_OK;
+        if (L.nx) return native_exchange(h, l, kind, pa, pb, L.hbuf->d);
+        int rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 0);
+        if (!rc) rc = h->halo_fused(h->halo_user, l, kind, pa, pb, L.hbuf->d, 1);
+        return rc ? mgs_fail(ctx, MGS_ERR_STATE, "fused halo exchange failed at level %d (%d)", l, rc) : MGS_OK;
+      };
+      MGS_TRY(payload(0, L.wd->d, b));
+      MGS_TRY(mgs_launch_group_pre(&Ahat, L.grp, L.T, b, b, L.r->d, L.tmp->d, C.b->d, hv, L.A->rows));
       MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
+      MGS_TRY(payload(1, C.x->d, L.T->agg));
+      if (halo) return mgs_launch_coded_range(&Amap, FUSE_POST_MAPPED, C.x->d, L.r->d, L.wd->d, 0.0, nullptr, L.T->agg, x, hv, L.T->n_coarse, 0, nb);
       return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, nullptr, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
     }
     // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
@@ -886,7 +899,7 @@ static int prepare_fused(mgs_hier *h) {
           MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg,
                                     ctx->opt_valcode ? L.A->val : nullptr));
       }
-      if (ctx->opt_fuse_restrict && !L.grp_tried && !shard) {   // row-block groups of the grouped pre pass (null: level does not qualify)
+      if (ctx->opt_fuse_restrict && !L.grp_tried) {   // row-block groups of the grouped pre pass (null: level does not qualify)
         L.grp_tried = true; MGS_TRY(mgs_build_groups(ctx, L.A, L.T, &L.grp)); drop_graph(h);
       }
       // codes whose tuples depend on Â's values (or, on a shard, on the halo tags) follow val_wd

@@ -45,7 +45,8 @@ def main():
     n_loc, n_ext = A.shape
     sh = mgd.ShardedHierarchy(ctx, A, plan0, 0.6, 1, 1, comm)
     sh.overlap_min_rows = 0   # exercise the asynchronous form on every level
-    ctx.set_option("split_min_rows", 0 if N != 24 else 400000)   # ... and the interior/boundary split (N = 24: the exchange-then-one-launch form)
+    if "split_min_rows" not in os.environ.get("MGS_OPTIONS", ""):
+        ctx.set_option("split_min_rows", 0 if N != 24 else 400000)   # ... and the interior/boundary split (N = 24: the exchange-then-one-launch form)
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=100, overlap=overlap, fused=fused)
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     if os.environ.get("MGS_NATIVE_RCCL") == "force":
@@ -113,7 +114,8 @@ def main():
     assert res <= 1.5e-10, res
     dist.barrier()
     if rank == 0:
-        print(f"DIST_OK world={world} N={N} sharded_levels={len(sh.plans)} total_levels={sh.nlev} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
+        ngrp = sum(1 for l in range(len(sh.plans) - 1) if sh.h.group_info(l)["groups"] > 0)
+        print(f"DIST_OK world={world} N={N} grouped_levels={ngrp} sharded_levels={len(sh.plans)} total_levels={sh.nlev} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
     del sh, b, x, xs, y, xsol, A
     ctx.close()
     dist.destroy_process_group()

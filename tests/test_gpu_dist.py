@@ -24,6 +24,22 @@ def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 3000, 0), (3, 36, 2000, 0), (2, 40, 3000, 1), (3, 36, 2000, 1)])
+def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
+    """the grouped pre pass (restriction inside the pre pass, t-form post pass) on row shards — halo payload exchanged first, halo-tagged
+    pattern codes — forced onto these small grids (group_min_blocks=1, 60 % strays allowed); callback transport and native transport
+    (stand-in RCCL); cycle vs the oracle, solve to 1e-10"""
+    fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_OPTIONS="group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000")
+    if native:
+        env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    port = 29750 + (os.getpid() % 1000) + world + 10 * native
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout and "grouped_levels=" in r.stdout and "grouped_levels=0" not in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
 @pytest.mark.parametrize("world,N,tail", [(2, 20, 1500), (3, 18, 800), (4, 18, 600), (2, 40, 3000)])
 def test_native_transport_multi_rank_matches_oracle(world, N, tail):
     """the NATIVE transport of the C++ cycle (ncclSend/ncclRecv groups, tail all-gather, all-reduced dots) with several

@@ -148,11 +148,12 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
     b = ctx.vec(n).rand(seed=3)
     try:
         ctx.set_option("group_stray_pct", 60)                # small grids: many aggregates leave their group — exercise that path too
+        ctx.set_option("group_min_blocks", 1)
         ctx.set_option("fuse_restrict", 1); xg = h.vcycle(b).numpy()
         info = [h.group_info(l) for l in range(h.nlev - 1)]
         ctx.set_option("fuse_restrict", 0); xs = h.vcycle(b).numpy()
     finally:
-        ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6)
+        ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6); ctx.set_option("group_min_blocks", 1024)
     assert info[0]["groups"] > 0, info                      # the device matching numbers aggregates by their leader: level 0 qualifies
     assert rel(xg, xs) <= 1e-13, (rel(xg, xs), info)
     # oracle cycle on the downloaded hierarchy
