@@ -272,6 +272,14 @@ int mgs_time_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int reps, double 
  * row-block kernel, [4]=leading and [5]=trailing row blocks that read halo columns, [6]=1 if the
  * interior/boundary split is usable, [7]=1 if some block takes the long-row path.            */
 int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]);
+/* "origin" of the rows of a coarse operator built by the device setup: the finest-level row each row descends from (leader of its
+ * aggregate, chained through the levels).  The pairwise matching breaks ties between equally strong neighbours in that index space
+ * (nearest first, then even multiples of the stride), which keeps aggregates aligned on grid-like problems on every level.  A row-sharded
+ * hierarchy hands the origins of its last sharded level (shifted to global finest-level rows) to the replicated tail with these two
+ * calls.  get: returns 1 and writes nothing when the operator carries none (= identity).  No reference counterpart (the reference's
+ * sequential matching scans neighbours in index order, AGMG.cpp:149-179). */
+int mgs_csr_get_origin(const mgs_csr *A, int *origin_host);
+int mgs_csr_set_origin(mgs_csr *A, const int *origin_host);
 /* ---- native RCCL transport of a row-sharded hierarchy (no reference counterpart: the reference is single-process) ----
  * One communicator per process/GPU.  librccl is resolved at run time from `librccl_path` — pass the copy the launcher
  * already loaded (for torch.distributed: <torch>/lib/librccl.so) so the process holds a single RCCL instance.  Rank 0

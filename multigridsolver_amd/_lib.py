@@ -35,6 +35,8 @@ PROTOTYPES = {
     "mgs_csr_download": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_dbl_p]),
     "mgs_csr_shape": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_i64_p]),
     "mgs_csr_plan_info": (C.c_int, [C.c_void_p, c_i64_p]),
+    "mgs_csr_get_origin": (C.c_int, [C.c_void_p, c_int_p]),
+    "mgs_csr_set_origin": (C.c_int, [C.c_void_p, c_int_p]),
     "mgs_comm_unique_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "mgs_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mgs_comm_destroy": (C.c_int, [C.c_void_p]),

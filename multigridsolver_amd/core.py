@@ -135,6 +135,18 @@ class Csr:
         keys = ["max_block_nnz", "max_row_len", "far_band", "lds_bytes", "halo_lo_blocks", "halo_hi_blocks", "halo_split_ok", "has_long_row_blocks"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def origin(self):
+        """finest-level row every row descends from (None: identity) — tie-break space of the device matching"""
+        out = np.empty(max(self.shape[0], 1), dtype=np.int32)
+        rc = lib().mgs_csr_get_origin(self.h, _ip(out))
+        if rc == 1:
+            return None
+        check(rc, self.ctx.h); return out[: self.shape[0]]
+
+    def set_origin(self, origin):
+        o = np.ascontiguousarray(origin, dtype=np.int32)
+        check(lib().mgs_csr_set_origin(self.h, _ip(o)), self.ctx.h); return self
+
     def optimize(self):
         """build the pattern code of the column array (mgs_csr_optimize); returns self"""
         check(lib().mgs_csr_optimize(self.h), self.ctx.h); return self

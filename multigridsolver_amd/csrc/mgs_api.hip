@@ -206,6 +206,21 @@ int mgs_csr_plan_info(const mgs_csr *A, int64_t out[8]) {
   out[4] = A->halo_lo_blocks; out[5] = A->halo_hi_blocks; out[6] = A->halo_split_ok ? 1 : 0; out[7] = A->max_block_nnz > A->lds_cap ? 1 : 0;
   return MGS_OK;
 }
+int mgs_csr_get_origin(const mgs_csr *A, int *origin) {
+  mgs_ctx *ctx = A->ctx;
+  if (!A->origin) return 1;                       // identity (no origin recorded): nothing written
+  MGS_HIP(ctx, hipMemcpyAsync(origin, A->origin, sizeof(int) * (size_t)A->rows, hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MGS_OK;
+}
+int mgs_csr_set_origin(mgs_csr *A, const int *origin) {
+  mgs_ctx *ctx = A->ctx;
+  if (A->origin) { hipFree(A->origin); A->origin = nullptr; }
+  if (!origin || A->rows == 0) return MGS_OK;
+  MGS_TRY(mgs_dev_alloc(ctx, &A->origin, (size_t)A->rows));
+  MGS_HIP(ctx, hipMemcpy(A->origin, origin, sizeof(int) * (size_t)A->rows, hipMemcpyHostToDevice));
+  return MGS_OK;
+}
 int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
   if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }

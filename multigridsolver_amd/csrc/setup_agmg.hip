@@ -485,18 +485,20 @@ __global__ void colmap_ext_kernel(int n, int n_ext, int nc, const int *__restric
 int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out) {
   mgs_ctx *ctx = A->ctx;
   MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows <= A->cols, MGS_ERR_INVALID, "galerkin: shape mismatch");
-  if (A->rows == A->cols) return galerkin_core(A, T->n_coarse, T->cptr, T->members, T->agg, T->n_coarse, out);
+  auto inherit = [&]() -> int {     // the coarse rows keep their origins (tie-break space of the next level's matching)
+    if (!T->corigin || T->n_coarse <= 0) return MGS_OK;
+    MGS_TRY(mgs_dev_alloc(ctx, &(*out)->origin, (size_t)T->n_coarse));
+    MGS_HIP(ctx, hipMemcpyAsync((*out)->origin, T->corigin, sizeof(int) * (size_t)T->n_coarse, hipMemcpyDeviceToDevice, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MGS_OK;
+  };
+  if (A->rows == A->cols) { MGS_TRY(galerkin_core(A, T->n_coarse, T->cptr, T->members, T->agg, T->n_coarse, out)); return inherit(); }
   DevBuf cm;
   MGS_TRY(dalloc<int>(ctx, cm, (size_t)A->cols));
   const int n_halo = A->cols - A->rows;
   hipLaunchKernelGGL(colmap_ext_kernel, dim3(mgs_grid(A->cols, TB)), dim3(TB), 0, ctx->stream, A->rows, A->cols, T->n_coarse, T->agg, halo_map_dev, cm.as<int>());
   MGS_TRY(galerkin_core(A, T->n_coarse, T->cptr, T->members, cm.as<int>(), T->n_coarse + (halo_map_dev ? n_halo_c : n_halo), out));
-  if (T->corigin && T->n_coarse > 0) {      // row shard: the coarse shard's rows keep their origins (local finest-level rows)
-    MGS_TRY(mgs_dev_alloc(ctx, &(*out)->origin, (size_t)T->n_coarse));
-    MGS_HIP(ctx, hipMemcpyAsync((*out)->origin, T->corigin, sizeof(int) * (size_t)T->n_coarse, hipMemcpyDeviceToDevice, ctx->stream));
-    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  return MGS_OK;
+  return inherit();
 }
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) { return k_galerkin_agg_ext(A, T, nullptr, 0, out); }
 

@@ -486,11 +486,17 @@ class ShardedHierarchy:
         offs = np.concatenate([[0], np.cumsum(nlocs)]).astype(np.int64)
         rp, ci, v = self.h.level_A(L).download()
         mine = shard_to_global(plan, rp, ci, v, offs, comm.rank)
-        parts = comm.all_gather_object((mine.indptr, mine.indices, mine.data))
-        Ag = sps.vstack([sps.csr_matrix((d, i, p), shape=(len(p) - 1, int(offs[-1]))) for (p, i, d) in parts]).tocsr()
+        # origins of the rows (tie-break space of the matching) travel with the operator, shifted to global finest-level rows
+        org = self.h.level_A(L).origin() if L > 0 else None
+        n0 = comm.allgather_ints(self.plans[0].n_loc)
+        off0 = int(np.concatenate([[0], np.cumsum(n0)])[comm.rank])
+        parts = comm.all_gather_object((mine.indptr, mine.indices, mine.data, None if org is None else org.astype(np.int64) + off0))
+        Ag = sps.vstack([sps.csr_matrix((d, i, p), shape=(len(p) - 1, int(offs[-1]))) for (p, i, d, _) in parts]).tocsr()
         Ag.sort_indices()
         n_t = Ag.shape[0]
         self.tail_A = ctx.csr(n_t, n_t, Ag.indptr, Ag.indices, Ag.data)
+        if all(q[3] is not None for q in parts) and int(np.sum(n0)) < 2 ** 31:
+            self.tail_A.set_origin(np.concatenate([q[3] for q in parts]).astype(np.int32))
         self.tail = core.Hierarchy(self.tail_A, *self.smoother).coarsen(ktg, npass, tou, coarse_rows, 32).finalize()
         if log:
             log(f"replicated tail from level {L}: {n_t} global rows, {self.tail.nlev} levels")
