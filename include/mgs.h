@@ -177,6 +177,11 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
  * by two GCR steps preconditioned by the cycle below instead of one recursive cycle.  0 = V-cycle
  * (default).  Scalars stay on the device; ignored on row-sharded hierarchies.               */
 int mgs_hier_set_kcycle(mgs_hier *h, int levels);
+/* the additive switch of MultiGridPrecond::solve (reference src/common/bicg.cpp:59, `multiplicative_precond = false`; dead in the
+ * reference — the constructor fixes it to true, :42): with on != 0 a zero-guess cycle returns, level by level,
+ * P·cycle(Pᵀ v) + M2(v) with M2 = ωD⁻¹ instead of the multiplicative form.  The other switch, `use_preconditioner = false`
+ * (:53-54, solve(v) = v), is mgs_bicgstab / mgs_fgcr with hier = NULL.  Not offered on row shards. */
+int mgs_hier_set_additive(mgs_hier *h, int on);
 int mgs_hier_destroy(mgs_hier *h);
 int mgs_hier_nlev(const mgs_hier *h);
 int mgs_hier_level_shape(const mgs_hier *h, int level, int *rows, int64_t *nnz);

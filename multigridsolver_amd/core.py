@@ -309,6 +309,10 @@ class Hierarchy:
     def set_kcycle(self, levels):
         check(lib().mgs_hier_set_kcycle(self.h, levels), self.ctx.h); return self
 
+    def set_additive(self, on=True):
+        """additive form of solve() (reference bicg.cpp:59)"""
+        check(lib().mgs_hier_set_additive(self.h, int(bool(on))), self.ctx.h); return self
+
     @property
     def nlev(self):
         return lib().mgs_hier_nlev(self.h)

@@ -5,6 +5,7 @@
 // preconditioner, fills b with srand(0)/rand() (bicg.cpp:139,159-162), runs BiCGSTABiml with
 // tol 1e-6 and max_iter 10000 (bicg.cpp:148,164) and prints the reference's two [info] lines.
 // Environment knobs (new; the reference has no smoother options): MGS_OMEGA, MGS_NU1, MGS_NU2,
+// MGS_ADDITIVE=1 / MGS_NO_PRECOND=1 (the reference's two dead solve() switches, bicg.cpp:42-43,53-59),
 // MGS_TOL, MGS_MATRIX_DIR, MGS_GENERIC=1 (run the generic operator-overloading BiCGSTABiml
 // template instead of the fused device path).
 #include "mgs_host.hpp"
@@ -28,6 +29,8 @@ int main(int argc, char **argv) {
     if ((e = getenv("MGS_OMEGA"))) opt.omega = atof(e);
     if ((e = getenv("MGS_NU1"))) opt.nu1 = atoi(e);
     if ((e = getenv("MGS_NU2"))) opt.nu2 = atoi(e);
+    if ((e = getenv("MGS_ADDITIVE"))) opt.multiplicative_precond = atoi(e) == 0;      // the reference's two dead switches (bicg.cpp:42-43)
+    if ((e = getenv("MGS_NO_PRECOND"))) opt.use_preconditioner = atoi(e) == 0;
 
     SMatrix A = readMatrix(dir + matrix_name + string(".mtx"));
     DeviceMatrix Ad(A);
@@ -40,17 +43,17 @@ int main(int argc, char **argv) {
 
     VectorXd x(A.rows());
     x.setZero();
-    std::vector<double> bh((size_t)A.rows());
     srand(0);   // the reference draws nothing between srand(0) (:139) and this loop; runtime start-up here might
-    for (int i = 0; i < A.rows(); i++) bh[i] = rand() / (RAND_MAX + 0.0);
     VectorXd b(A.rows());
-    b.upload(bh);
+    for (int i = 0; i < A.rows(); i++) {       // bicg.cpp:159-162, statement for statement (host-staged element access)
+      b[i] = rand() / (RAND_MAX + 0.0);
+    }
 
     int max_iter = 10000;
     TicToc solverTimer("BiCGStab_SolveTimer", 4);
     solverTimer.tic();
     int status = getenv("MGS_GENERIC") ? BiCGSTABiml<DeviceMatrix, VectorXd, MultiGridPrecond, double>(Ad, x, b, *precond, max_iter, tol)
-                                       : BiCGSTABiml(Ad, x, b, *precond, max_iter, tol);
+                                       : BiCGSTABiml(A, x, b, *precond, max_iter, tol);     // bicg.cpp:168 as written (A = the host SMatrix)
     solverTimer.toc();
 
     if (status == 0) {

@@ -70,30 +70,48 @@ inline void writeMatrix(std::string filename, const SMatrix &A) {   // MatrixIO.
 // Value semantics like Eigen::VectorXd (copies are deep); arithmetic runs on the device.
 class Vector {
   std::shared_ptr<mgs_vec> v_;
+  // Host staging for element access (`b[i] = …`, `x(0)`: bicg.cpp:78,159-162).  The first access downloads the vector once;
+  // writes mark the mirror dirty and the next device use (handle()) uploads it.  Plain device arithmetic never touches it.
+  mutable std::vector<double> host_;
+  mutable bool host_valid_ = false, host_dirty_ = false;
   static std::shared_ptr<mgs_vec> make(int64_t n) {
     mgs_vec *p = nullptr; check(mgs_vec_create(context(), n, &p), context());
     return std::shared_ptr<mgs_vec>(p, [](mgs_vec *q) { mgs_vec_destroy(q); });
   }
+  void flush() const {
+    if (host_dirty_) { check(mgs_vec_upload(v_.get(), host_.data(), (int64_t)host_.size()), context()); host_dirty_ = false; }
+  }
+  double *stage() const {
+    if (!host_valid_) { host_.resize((size_t)size()); if (size()) check(mgs_vec_download(v_.get(), host_.data(), size()), context()); host_valid_ = true; }
+    return host_.data();
+  }
  public:
   Vector() {}
   explicit Vector(int64_t n) : v_(make(n)) {}
-  Vector(const Vector &o) { if (o.v_) { v_ = make(o.size()); check(mgs_vec_copy(o.v_.get(), v_.get()), context()); } }
+  Vector(const Vector &o) { if (o.v_) { v_ = make(o.size()); check(mgs_vec_copy(o.handle(), v_.get()), context()); } }
   Vector(Vector &&) = default;
-  Vector &operator=(const Vector &o) { if (this != &o) { Vector t(o); v_ = std::move(t.v_); } return *this; }
+  Vector &operator=(const Vector &o) { if (this != &o) { Vector t(o); v_ = std::move(t.v_); host_valid_ = host_dirty_ = false; } return *this; }
   Vector &operator=(Vector &&) = default;
   int64_t size() const { return v_ ? mgs_vec_size(v_.get()) : 0; }
   int64_t rows() const { return size(); }
-  mgs_vec *handle() const { return v_.get(); }
-  void setZero() { check(mgs_vec_fill(v_.get(), 0.0), context()); }
-  void upload(const std::vector<double> &h) { check(mgs_vec_upload(v_.get(), h.data(), (int64_t)h.size()), context()); }
-  std::vector<double> download() const { std::vector<double> h((size_t)size()); check(mgs_vec_download(v_.get(), h.data(), size()), context()); return h; }
-  double dot(const Vector &o) const { double s; check(mgs_dot(v_.get(), o.v_.get(), &s), context()); return s; }
-  double norm() const { double s; check(mgs_nrm2(v_.get(), &s), context()); return s; }
-  Vector &operator+=(const Vector &o) { check(mgs_axpby(1.0, o.v_.get(), 1.0, v_.get()), context()); return *this; }
-  Vector &operator-=(const Vector &o) { check(mgs_axpby(-1.0, o.v_.get(), 1.0, v_.get()), context()); return *this; }
-  friend Vector operator+(const Vector &a, const Vector &b) { Vector r(a.size()); check(mgs_axpbypcz(1.0, a.v_.get(), 1.0, b.v_.get(), 0.0, r.v_.get()), context()); return r; }
-  friend Vector operator-(const Vector &a, const Vector &b) { Vector r(a.size()); check(mgs_axpbypcz(1.0, a.v_.get(), -1.0, b.v_.get(), 0.0, r.v_.get()), context()); return r; }
-  friend Vector operator*(double s, const Vector &a) { Vector r(a.size()); check(mgs_axpby(s, a.v_.get(), 0.0, r.v_.get()), context()); return r; }
+  // device handle for reading: pending element writes are uploaded first
+  mgs_vec *handle() const { flush(); return v_.get(); }
+  // device handle for writing: the host mirror no longer reflects the device
+  mgs_vec *out() { flush(); host_valid_ = false; return v_.get(); }
+  double &operator[](int64_t i) { double *h = stage(); host_dirty_ = true; return h[i]; }          // bicg.cpp:161
+  double operator[](int64_t i) const { return stage()[i]; }
+  double &operator()(int64_t i) { return (*this)[i]; }                                              // bicg.cpp:78 style access
+  double operator()(int64_t i) const { return (*this)[i]; }
+  void setZero() { check(mgs_vec_fill(out(), 0.0), context()); }
+  void upload(const std::vector<double> &h) { check(mgs_vec_upload(out(), h.data(), (int64_t)h.size()), context()); }
+  std::vector<double> download() const { std::vector<double> h((size_t)size()); check(mgs_vec_download(handle(), h.data(), size()), context()); return h; }
+  double dot(const Vector &o) const { double s; check(mgs_dot(handle(), o.handle(), &s), context()); return s; }
+  double norm() const { double s; check(mgs_nrm2(handle(), &s), context()); return s; }
+  Vector &operator+=(const Vector &o) { check(mgs_axpby(1.0, o.handle(), 1.0, out()), context()); return *this; }
+  Vector &operator-=(const Vector &o) { check(mgs_axpby(-1.0, o.handle(), 1.0, out()), context()); return *this; }
+  friend Vector operator+(const Vector &a, const Vector &b) { Vector r(a.size()); check(mgs_axpbypcz(1.0, a.handle(), 1.0, b.handle(), 0.0, r.out()), context()); return r; }
+  friend Vector operator-(const Vector &a, const Vector &b) { Vector r(a.size()); check(mgs_axpbypcz(1.0, a.handle(), -1.0, b.handle(), 0.0, r.out()), context()); return r; }
+  friend Vector operator*(double s, const Vector &a) { Vector r(a.size()); check(mgs_axpby(s, a.handle(), 0.0, r.out()), context()); return r; }
   friend Vector operator*(const Vector &a, double s) { return s * a; }
 };
 typedef Vector VectorXd;
@@ -113,7 +131,7 @@ class DeviceMatrix {
   int cols() const { return cols_; }
   mgs_csr *handle() const { return a_.get(); }
   Vector operator*(const Vector &x) const {            // bicg.cpp:57,82,107,117
-    Vector y(rows_); check(mgs_spmv(a_.get(), x.handle(), y.handle()), context()); return y;
+    Vector y(rows_); check(mgs_spmv(a_.get(), x.handle(), y.out()), context()); return y;
   }
 };
 
@@ -127,19 +145,25 @@ struct PrecondOptions {
   double omega = 0.6; int nu1 = 1, nu2 = 1;
   double ktg = 10.0; int npass = 2; double tou = 8.0;   // src/GPU_CUDAC++/results.txt:22-24
   int coarse_rows = 2500; int max_levels = 32;   // ≤ 2500 rows: dense inverse (a GEMV beats two more latency-bound levels)
+  // the two switches of the reference's solve() (bicg.cpp:42-43,53-59; both fixed to true there):
+  bool multiplicative_precond = true;   // false: multigrid_solve(v) + M2(v) (:59) with M2 = ωD⁻¹
+  bool use_preconditioner = true;       // false: solve(v) = v (:53-54)
 };
 class MultiGridPrecond {
   DeviceMatrix A_;
   std::shared_ptr<mgs_hier> h_;
+  bool use_preconditioner_ = true;
  public:
   typedef PrecondOptions Options;
   MultiGridPrecond(const SMatrix &A_in, const SMatrix &P_in, Options o = Options()) : A_(A_in) { build(A_, &P_in, o); }
   MultiGridPrecond(const DeviceMatrix &A_dev, const SMatrix *P_in, Options o = Options()) : A_(A_dev) { build(A_, P_in, o); }
   template <typename T> T solve(const T &vec) const {     // bicg.cpp:51-61
+    if (!use_preconditioner_) return vec;                  // :53-54
     T out(vec.size());
-    check(mgs_vcycle(h_.get(), vec.handle(), out.handle(), 1), context());
+    check(mgs_vcycle(h_.get(), vec.handle(), out.out(), 1), context());
     return out;
   }
+  bool use_preconditioner() const { return use_preconditioner_; }
   mgs_hier *handle() const { return h_.get(); }
   const DeviceMatrix &matrix() const { return A_; }
   int levels() const { return mgs_hier_nlev(h_.get()); }
@@ -151,6 +175,8 @@ class MultiGridPrecond {
     if (P) { DeviceMatrix Pd(*P); check(mgs_hier_push_P(h, Pd.handle()), context()); }
     check(mgs_hier_coarsen(h, o.ktg, o.npass, o.tou, o.coarse_rows, o.max_levels), context());
     check(mgs_hier_finalize(h), context());
+    if (!o.multiplicative_precond) check(mgs_hier_set_additive(h, 1), context());
+    use_preconditioner_ = o.use_preconditioner;
   }
 };
 
@@ -196,8 +222,13 @@ int BiCGSTABiml(const Matrix &A, Vec &x, const Vec &b, const Preconditioner &M, 
 // Device-resident fast path for the library's own types (no temporaries, fused updates):
 inline int BiCGSTABiml(const DeviceMatrix &A, Vector &x, const Vector &b, const MultiGridPrecond &M, int &max_iter, double &tol) {
   int status = -1;
-  check(mgs_bicgstab(A.handle(), x.handle(), b.handle(), M.handle(), &max_iter, &tol, &status), context());
+  check(mgs_bicgstab(A.handle(), x.out(), b.handle(), M.use_preconditioner() ? M.handle() : nullptr, &max_iter, &tol, &status), context());
   return status;
+}
+// the call exactly as the reference's main() writes it (bicg.cpp:168): A is the host SMatrix the preconditioner was built
+// from — its device copy lives in M
+inline int BiCGSTABiml(const SMatrix &, Vector &x, const Vector &b, const MultiGridPrecond &M, int &max_iter, double &tol) {
+  return BiCGSTABiml(M.matrix(), x, b, M, max_iter, tol);
 }
 
 // ---------------------------------------------------------------- TicToc.cpp:18-53

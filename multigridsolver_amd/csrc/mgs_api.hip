@@ -499,6 +499,11 @@ int mgs_hier_set_kcycle(mgs_hier *h, int levels) {
   h->kcycle_levels = levels; drop_graph(h);
   return MGS_OK;
 }
+int mgs_hier_set_additive(mgs_hier *h, int on) {
+  MGS_CHECK(h->ctx, !on || (!h->halo && !h->halo_begin && !h->native), MGS_ERR_STATE, "mgs_hier_set_additive: not offered on row shards");
+  h->additive = on != 0; drop_graph(h);
+  return MGS_OK;
+}
 int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user) { h->halo = fn; h->halo_user = user; drop_graph(h); return MGS_OK; }
 int mgs_hier_set_halo_exchange_split(mgs_hier *h, mgs_halo_fn begin, mgs_halo_fn end, void *user) {
   MGS_CHECK(h->ctx, (begin == nullptr) == (end == nullptr), MGS_ERR_INVALID, "split exchange needs both begin and end");
@@ -754,6 +759,17 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     return k_dense_gemv(ctx, h->nc, h->inv, b, x);
   }
   mgs_level &C = h->lev[l + 1];
+  if (h->additive) {
+    // additive form of solve(), reference src/common/bicg.cpp:59 with M2 = ωD⁻¹, level by level (zero guess only):
+    //   x = P·cycle(l+1, Pᵀ b) + ωD⁻¹ b
+    if (L.T->aggregation) MGS_TRY(k_restrict_agg(ctx, L.T->n_coarse, L.T->cptr, L.T->members, b, C.b->d));
+    else MGS_TRY(mgs_launch_csr_op(L.T->Pt, MGS_OP_SPMV, b, nullptr, nullptr, 0.0, C.b->d));
+    MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
+    if (L.T->aggregation) MGS_TRY(k_prolong_agg(ctx, n, L.T->agg, C.x->d, x, 0));
+    else MGS_TRY(mgs_launch_csr_op(L.T->P, MGS_OP_SPMV, C.x->d, nullptr, nullptr, 0.0, x));
+    MGS_TRY(k_jacobi_zero(ctx, n, h->omega, L.dinv->d, b, L.tmp->d));
+    return k_axpby(ctx, n, 1.0, L.tmp->d, 1.0, x);
+  }
   // ---- fused form (square unsharded level, aggregation P, V(1,1) from x = 0): two matrix passes,
   //      no separate (ωD⁻¹)b / prolong-add kernels
   const bool sharded = h->halo || h->halo_begin || h->native;
@@ -938,6 +954,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   mgs_level &L0 = h->lev[0];
   MGS_CHECK(ctx, b->n >= L0.n && x->n >= L0.n, MGS_ERR_INVALID, "mgs_vcycle: vectors shorter than the operator (%d rows)", L0.n);
   MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
+  MGS_CHECK(ctx, !h->additive || zero_guess, MGS_ERR_INVALID, "mgs_vcycle: the additive form (bicg.cpp:59) is a preconditioner application from x = 0 only");
   if (h->lev.size() == 1 && !h->coarse_sweeps) return cycle_level(h, 0, b->d, x->d, true);
   // sharded level 0 needs halo room behind the owned entries: work in the level's own buffer
   double *xw = x->d;

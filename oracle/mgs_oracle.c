@@ -308,6 +308,7 @@ struct orc_hier {
   orc_dense_lu lu;
   double omega; int nu1, nu2;
   int kcycle_levels;
+  int additive;   /* bicg.cpp:59: multigrid_solve(v) + M2(v) instead of the multiplicative form */
   double **kc1, **kv1, **kc2, **kv2, **kr;
 };
 
@@ -369,6 +370,7 @@ void orc_hier_destroy(orc_hier *h) {
 int orc_hier_nlev(const orc_hier *h) { return h->nlev; }
 void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2) { h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; }
 void orc_hier_set_kcycle(orc_hier *h, int levels) { h->kcycle_levels = levels; }
+void orc_hier_set_additive(orc_hier *h, int on) { h->additive = on; }
 const orc_csr *orc_hier_A(const orc_hier *h, int l) { return &h->A[l]; }
 
 /* V-cycle definition (SURVEY §7 "Hard parts"; two-level ν1=0, ν2=1 from x=0
@@ -407,8 +409,15 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
   const orc_csr *A = &h->A[l];
   int n = A->rows;
   if (l == h->nlev - 1) { orc_dense_lu_solve(&h->lu, b, x); return; }
-  if (zero_guess) for (int i = 0; i < n; i++) x[i] = 0.0;
   double *tmp = h->tmp[l], *r = h->r[l];
+  if (h->additive) {   /* bicg.cpp:59 with M2 = ωD⁻¹, level by level:  x = P·cycle(Pᵀ b) + ωD⁻¹ b  (zero guess only) */
+    orc_spmv(&h->Pt[l], b, h->bc[l + 1]);
+    coarse_solve_rec(h, l + 1, h->bc[l + 1], h->xc[l + 1]);
+    orc_spmv(&h->P[l], h->xc[l + 1], tmp);
+    for (int i = 0; i < n; i++) x[i] = tmp[i] + (h->omega * h->dinv[l][i]) * b[i];
+    return;
+  }
+  if (zero_guess) for (int i = 0; i < n; i++) x[i] = 0.0;
   for (int s = 0; s < h->nu1; s++) {
     orc_jacobi(A, h->dinv[l], h->omega, b, x, tmp);
     memcpy(x, tmp, sizeof(double) * (size_t)n);

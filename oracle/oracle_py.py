@@ -55,6 +55,7 @@ def lib():
         L.orc_hier_nlev.argtypes = [C.c_void_p]
         L.orc_hier_set_smoother.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]; L.orc_hier_set_smoother.restype = None
         L.orc_hier_set_kcycle.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_kcycle.restype = None
+        L.orc_hier_set_additive.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_additive.restype = None
         L.orc_hier_A.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_A.restype = cp
         L.orc_vcycle.argtypes = [C.c_void_p, dp, dp, C.c_int]; L.orc_vcycle.restype = None
         L.orc_bicgstab.argtypes = [cp, dp, dp, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -240,6 +241,11 @@ class Hier:
 
     def set_kcycle(self, levels):
         lib().orc_hier_set_kcycle(self.h, levels)
+        return self
+
+    def set_additive(self, on=True):
+        """additive form, reference src/common/bicg.cpp:59 (with M2 = ωD⁻¹)"""
+        lib().orc_hier_set_additive(self.h, int(bool(on)))
         return self
 
     def A(self, l):

@@ -72,8 +72,10 @@ struct JacobiTwoGrid {
     lu.analyzePattern(Ac); lu.factorize(Ac);            // bicg.cpp:35-36
     dinv = A.diagonal().cwiseInverse();
   }
+  bool additive = false;
   template <typename T> T solve(const T &v) const {
     T res = P * (lu.solve(Pt * v));                     // bicg.cpp:48
+    if (additive) return res + omega * dinv.cwiseProduct(v);   // bicg.cpp:59 with M2 = ωD⁻¹
     T r = v - A * res;
     return res + omega * dinv.cwiseProduct(r);          // bicg.cpp:57 with M2 = ωD⁻¹
   }
@@ -152,6 +154,10 @@ int main(int argc, char **argv) {
       fprintf(f, "%d %d %.17g\n", st, it, tol); fclose(f);
       snprintf(nm, sizeof nm, "x_bicg_jac_w%02d", (int)(w * 10 + 0.5));
       dump_vec(out, nm, x);
+      if (w == 0.5) {                                              // the additive switch of solve(), bicg.cpp:59
+        J.additive = true;
+        dump_vec(out, "jac2grid_add_w05_b", J.solve(b));
+      }
     }
     {
       IdentityPrecond I; VectorXd x = VectorXd::Zero(n); int it = 10000; double tol = 1e-8;

@@ -77,6 +77,12 @@ def test_primitives_vs_reference_golden(ctx, mg, orc, inputs, golden, case, Anam
     for w, key in [(0.5, "jac2grid_w05_b"), (0.8, "jac2grid_w08_b")]:
         h.set_smoother(w, 0, 1)
         assert rel(h.vcycle(b).numpy(), g[key]) <= 1e-10
+    # the additive switch of solve() (bicg.cpp:59): multigrid_solve(v) + M2(v), M2 = ωD⁻¹ — against the Eigen harness
+    h.set_smoother(0.5, 0, 1).set_additive(True)
+    assert rel(h.vcycle(b).numpy(), g["jac2grid_add_w05_b"]) <= 1e-10
+    with pytest.raises(mg.MgsError):
+        h.vcycle(b, ctx.vec(n), zero_guess=False)           # a preconditioner application from x = 0 only
+    h.set_additive(False)
     # BiCGSTAB preconditioned by that cycle vs the reference's BiCGSTABiml run
     for w, tag in [(0.5, "w05"), (0.8, "w08")]:
         h.set_smoother(w, 0, 1)
@@ -116,6 +122,8 @@ def test_bundled_operators_vs_reference_golden(ctx, mg, orc, inputs, golden, nam
     assert np.array_equal(rp, g["Ac_rowptr"]) and np.array_equal(ci, g["Ac_col"]) and rel(v, g["Ac_val"]) <= 1e-14
     h = mg.Hierarchy(A, 0.5, 0, 0).push_P(P).finalize()
     assert rel(h.vcycle(b).numpy(), g["mg_solve_b"]) <= 1e-10
+    assert rel(h.set_smoother(0.5, 0, 1).set_additive(True).vcycle(b).numpy(), g["jac2grid_add_w05_b"]) <= 1e-10      # bicg.cpp:59
+    h.set_additive(False)
     for w, tag in [(0.5, "w05"), (0.8, "w08")]:
         h.set_smoother(w, 0, 1)
         assert rel(h.vcycle(b).numpy(), g[f"jac2grid_{tag}_b"]) <= 1e-10
@@ -403,7 +411,9 @@ def test_cpp_dropin_driver(orc, inputs, golden, tmp_path):
     shutil.copy(inputs["poisson10000"], root / "matrices" / "poisson10000.mtx")
     shutil.copy(inputs["poisson10000promatrix"], root / "matrices" / "poisson10000promatrix_cpu.mtx")
     Ao = orc.Csr.read(inputs["poisson10000"]); b = orc.rand_rhs(10000)
-    for extra, tag in [({}, "cpu"), ({"MGS_GENERIC": "1"}, "cpu"), ({}, "device")]:
+    # MGS_ADDITIVE / MGS_NO_PRECOND: the two switches of the reference's solve() (bicg.cpp:42-43,53-59), dead there, offered here
+    for extra, tag in [({}, "cpu"), ({"MGS_GENERIC": "1"}, "cpu"), ({}, "device"), ({"MGS_ADDITIVE": "1"}, "cpu"), ({"MGS_NO_PRECOND": "1"}, "cpu"),
+                       ({"MGS_NO_PRECOND": "1", "MGS_GENERIC": "1"}, "cpu")]:
         dump = str(tmp_path / "x.bin")
         env = dict(os.environ, MGS_DUMP_X=dump, **extra)
         r = subprocess.run([exe, "poisson10000", tag], cwd=root / "src" / "common", capture_output=True, text=True, env=env, timeout=300)
@@ -411,7 +421,7 @@ def test_cpp_dropin_driver(orc, inputs, golden, tmp_path):
         assert "Read matrix from file: ../../matrices/poisson10000.mtx" in r.stderr and "[time] " in r.stderr and "BiCGStab_SolveTimer" in r.stderr
         m_tol = re.search(r"\[info\] .*Tolerance\s+: ([0-9.eE+-]+)\.\n", r.stdout); m_it = re.search(r"Number of iterations BICG\s+: (\d+)\.", r.stdout)
         assert m_tol and m_it, r.stdout
-        assert float(m_tol.group(1)) < 1e-6 and 1 <= int(m_it.group(1)) < 100
+        assert float(m_tol.group(1)) < 1e-6 and 1 <= int(m_it.group(1)) < (100 if "MGS_NO_PRECOND" not in extra else 1000)
         x = np.fromfile(dump, dtype="<f8")
         assert np.linalg.norm(Ao.residual(x, b)) / np.linalg.norm(b) < 1.5e-6
     r = subprocess.run([exe], capture_output=True, text=True)

@@ -15,8 +15,13 @@ tag = sys.argv[1]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n = N ** 3
 nnz = 7 * n - 6 * N * N
-nc1 = None
-ALG = {"fused_pre": 12 * nnz + 28 * n + 4, "fused_post": 12 * nnz + 40 * n + 4, "spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
+# level-1 rows of the device-built hierarchy (aggregates of 4, a few odd shapes at the domain boundary): n/4 to within 1e-5 —
+# enters only the 8·n_c term of the post pass and the restriction terms of the grouped pre pass
+nc1 = n // 4
+# grouped_pre = pre pass + restriction (SURVEY §8d-d3 formulas) in one kernel
+ALG = {"fused_pre": 12 * nnz + 28 * n + 4, "fused_post": 12 * nnz + 40 * n + 8 * nc1 + 4,
+       "grouped_pre": (12 * nnz + 28 * n + 4) + (4 * (nc1 + 1) + 12 * n + 8 * nc1),
+       "spmv": 12 * nnz + 20 * n + 4, "residual": 12 * nnz + 28 * n + 4, "jacobi": 12 * nnz + 36 * n + 4,
        "axpby(calibration)": 32 * n}
 
 
@@ -34,6 +39,7 @@ def classify(name):
     for pre in ("csr_rowblock_kernel<", "csr_rowblock_slice_kernel<", "csr_rowblock_coded_kernel<"):
         if s.startswith(pre):
             return {"0": "spmv", "1": "residual", "2": "jacobi", "5": "fused_post"}.get(s[len(pre)], None)
+    if s.startswith("csr_group_pre_kernel<"): return "grouped_pre"
     if s.startswith("csr_rowblock_fused_kernel<3"): return "fused_pre"
     if s.startswith("csr_rowblock_fused_kernel<4") or s.startswith("csr_rowblock_fused_kernel<5"): return "fused_post"
     if s.startswith("axpbypcz_kernel"): return "axpby(calibration)"
@@ -45,7 +51,7 @@ trace = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kerne
 fine = collections.defaultdict(list)   # fine-level dispatches only (grid covers n rows)
 for r in trace:
     k = classify(r["Kernel_Name"])
-    if k and (int(r["Grid_Size_X"]) >= n or k.startswith("axpby")):
+    if k and (int(r["Grid_Size_X"]) >= (n // 8 if k == "grouped_pre" else n) or k.startswith("axpby")):
         fine[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 
@@ -53,7 +59,7 @@ def pmc(sub, counter):
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(os.path.join(src, sub, "*", "*_counter_collection.csv")))):
         k = classify(r["Kernel_Name"])
-        if k and r["Counter_Name"] == counter and (int(r["Grid_Size"]) >= n or k.startswith("axpby")):
+        if k and r["Counter_Name"] == counter and (int(r["Grid_Size"]) >= (n // 8 if k == "grouped_pre" else n) or k.startswith("axpby")):
             out[k].append(float(r["Counter_Value"]))
     return {k: sorted(v)[len(v) // 2] for k, v in out.items()}
 
@@ -63,7 +69,7 @@ fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 cal_read = 24 * n / (fetch["axpby(calibration)"] * 1024)
 cal_write = 8 * n / (write["axpby(calibration)"] * 1024)
 rows = []
-for k in [k for k in ["spmv", "residual", "jacobi", "fused_pre", "fused_post", "axpby(calibration)"] if k in fine and k in fetch and k in write]:
+for k in [k for k in ["spmv", "residual", "jacobi", "fused_pre", "grouped_pre", "fused_post", "axpby(calibration)"] if k in fine and k in fetch and k in write]:
     d = sorted(fine[k]); med = d[len(d) // 2]; avg = sum(d) / len(d)
     fb = fetch[k] * 1024 * cal_read; wb = write[k] * 1024 * cal_write
     rows.append({"kernel": k, "launches": len(d), "avg_us": avg / 1e3, "median_us": med / 1e3, "algorithmic_bytes": ALG[k],
