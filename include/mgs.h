@@ -175,7 +175,8 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
 /* K-cycle (docs/AGMG_For_Convection_Diffusion.pdf §3.1, Fortran `nlvcyc`
  * src/CPU_Matlab/dagtwolev_mex.f90:59-61,72): the coarse problems of levels 1..levels are solved
  * by two GCR steps preconditioned by the cycle below instead of one recursive cycle.  0 = V-cycle
- * (default).  Scalars stay on the device; ignored on row-sharded hierarchies.               */
+ * (default).  Scalars stay on the device.  On a row-sharded hierarchy the five inner products are summed over the
+ * ranks (mgs_ctx_set_native_allreduce, else the mgs_ctx_set_allreduce callback); without either the level runs a V-cycle. */
 int mgs_hier_set_kcycle(mgs_hier *h, int levels);
 /* the additive switch of MultiGridPrecond::solve (reference src/common/bicg.cpp:59, `multiplicative_precond = false`; dead in the
  * reference — the constructor fixes it to true, :42): with on != 0 a zero-guess cycle returns, level by level,

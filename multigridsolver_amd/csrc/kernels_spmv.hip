@@ -1045,10 +1045,14 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
   if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &c->tptr, (size_t)nblocks + 1);
   std::vector<int> h((size_t)nblocks + 1, 0);
   if (rc == MGS_OK) {
-    hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)nblocks + 1), ctx->stream);
-    hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, ints, val);
-    hipMemcpyAsync(h.data(), ints, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 1 failed");
+    hipError_t e = hipMemsetAsync(ints, 0, sizeof(int) * ((size_t)nblocks + 1), ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(rowcode_assign_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, ints, val);
+      e = hipGetLastError();                       // launch errors (bad configuration) surface here, not at the later sync
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), ints, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 1 failed: %s", hipGetErrorString(e));
   }
   if (rc == MGS_OK) {
     int64_t total = 0;
@@ -1062,12 +1066,15 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
       std::sort(sizes.begin(), sizes.end());
       c->tab_max = sizes.back();
       c->tab_cap = sizes[(size_t)((sizes.size() - 1) * 0.985)];
-      hipMemcpyAsync(c->tptr, h.data(), sizeof(int) * ((size_t)nblocks + 1), hipMemcpyHostToDevice, ctx->stream);
-      rc = mgs_dev_alloc(ctx, &c->tab, (size_t)total + 4);
+      hipError_t e = hipMemcpyAsync(c->tptr, h.data(), sizeof(int) * ((size_t)nblocks + 1), hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode table offsets: %s", hipGetErrorString(e));
+      if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &c->tab, (size_t)total + 4);
       if (rc == MGS_OK && val) rc = mgs_dev_alloc(ctx, &c->vtab, (size_t)total + 4);
       if (rc == MGS_OK) {
         hipLaunchKernelGGL(rowcode_fill_kernel, dim3(nblocks), dim3(RB), 0, ctx->stream, n, rowptr, idx, base, split, c->pid, isrep, c->tptr, c->tab, val, c->vtab);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 2 failed");
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "rowcode pass 2 failed: %s", hipGetErrorString(e));
       }
     }
   }

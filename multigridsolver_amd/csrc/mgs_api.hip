@@ -449,19 +449,26 @@ int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int 
   mgs_ctx *ctx = h->ctx;
   MGS_CHECK(ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d out of range", level);
   mgs_level &L = h->lev[level];
-  if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
+  auto free_plan = [](mgs_native_plan *P) { if (!P) return; if (P->send_idx) hipFree(P->send_idx); if (P->sendbuf) hipFree(P->sendbuf); delete P; };
+  free_plan(L.nx); L.nx = nullptr;
   drop_graph(h);
-  if (!c) { h->native = false; for (auto &q : h->lev) h->native = h->native || q.nx; return MGS_OK; }
+  h->native = false; for (auto &q : h->lev) h->native = h->native || q.nx;
+  if (!c) return MGS_OK;
+  // build and validate the plan aside; it is installed only when complete (a caller that handles the error keeps its callbacks)
   int world = 0; mgs_comm_size(c, &world, nullptr);
   mgs_native_plan *P = new mgs_native_plan();
   P->comm = c; P->scnt.assign(send_counts, send_counts + world); P->rcnt.assign(recv_counts, recv_counts + world);
   for (int p = 0; p < world; ++p) { P->ns += P->scnt[p]; P->nr += P->rcnt[p]; }
+  int rc = MGS_OK;
+  if (P->nr != (int64_t)L.A->cols - L.A->rows)
+    rc = mgs_fail(ctx, MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d has %d halo columns, plan delivers %lld", level, L.A->cols - L.A->rows, (long long)P->nr);
+  if (rc == MGS_OK && P->ns && !send_idx) rc = mgs_fail(ctx, MGS_ERR_INVALID, "mgs_hier_set_native_exchange: send_idx is NULL");
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &P->send_idx, (size_t)P->ns);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &P->sendbuf, (size_t)P->ns);
+  if (rc == MGS_OK && P->ns && hipMemcpy(P->send_idx, send_idx, sizeof(int) * (size_t)P->ns, hipMemcpyHostToDevice) != hipSuccess)
+    rc = mgs_fail(ctx, MGS_ERR_HIP, "mgs_hier_set_native_exchange: upload of the send list failed");
+  if (rc != MGS_OK) { free_plan(P); return rc; }
   L.nx = P;
-  MGS_CHECK(ctx, P->nr == (int64_t)L.A->cols - L.A->rows, MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d has %d halo columns, plan delivers %lld",
-            level, L.A->cols - L.A->rows, (long long)P->nr);
-  MGS_TRY(mgs_dev_alloc(ctx, &P->send_idx, (size_t)P->ns));
-  MGS_TRY(mgs_dev_alloc(ctx, &P->sendbuf, (size_t)P->ns));
-  if (P->ns) MGS_HIP(ctx, hipMemcpy(P->send_idx, send_idx, sizeof(int) * (size_t)P->ns, hipMemcpyHostToDevice));
   h->native = true;
   return MGS_OK;
 }
@@ -472,19 +479,23 @@ int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int
   if (!c || !tail) return MGS_OK;
   int world = 0, rank = 0; mgs_comm_size(c, &world, &rank);
   mgs_native_tail *T = new mgs_native_tail();
-  h->ntail = T;
+  h->ntail = T;                               // free_native_tail releases a half-built one on every error path below
+  auto fail = [&](int rc) { free_native_tail(h); return rc; };
   T->comm = c; T->tail = tail; T->n_loc = nlocs[rank];
   std::vector<int> gi;
   for (int p = 0; p < world; ++p) { T->maxn = std::max(T->maxn, nlocs[p]); }
   for (int p = 0; p < world; ++p) { if (p == rank) T->my_off = (int)gi.size(); for (int j = 0; j < nlocs[p]; ++j) gi.push_back(p * T->maxn + j); }
   T->n_t = (int)gi.size();
-  MGS_CHECK(ctx, T->n_t == tail->lev[0].n && T->n_loc == h->lev.back().n, MGS_ERR_INVALID, "mgs_hier_set_native_tail: tail has %d rows, shards sum to %d", tail->lev[0].n, T->n_t);
-  MGS_TRY(mgs_dev_alloc(ctx, &T->send, (size_t)std::max(T->maxn, 1)));
-  MGS_TRY(mgs_dev_alloc(ctx, &T->all, (size_t)std::max(T->maxn, 1) * world));
-  MGS_TRY(mgs_dev_alloc(ctx, &T->gidx, (size_t)T->n_t));
-  MGS_HIP(ctx, hipMemset(T->send, 0, sizeof(double) * (size_t)std::max(T->maxn, 1)));
-  MGS_HIP(ctx, hipMemcpy(T->gidx, gi.data(), sizeof(int) * gi.size(), hipMemcpyHostToDevice));
-  MGS_TRY(mgs_vec_create(ctx, T->n_t, &T->b)); MGS_TRY(mgs_vec_create(ctx, T->n_t, &T->x));
+  if (!(T->n_t == tail->lev[0].n && T->n_loc == h->lev.back().n))
+    return fail(mgs_fail(ctx, MGS_ERR_INVALID, "mgs_hier_set_native_tail: tail has %d rows, shards sum to %d", tail->lev[0].n, T->n_t));
+  int rc = mgs_dev_alloc(ctx, &T->send, (size_t)std::max(T->maxn, 1));
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &T->all, (size_t)std::max(T->maxn, 1) * world);
+  if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &T->gidx, (size_t)std::max(T->n_t, 1));
+  if (rc == MGS_OK && hipMemset(T->send, 0, sizeof(double) * (size_t)std::max(T->maxn, 1)) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "native tail: memset failed");
+  if (rc == MGS_OK && T->n_t && hipMemcpy(T->gidx, gi.data(), sizeof(int) * gi.size(), hipMemcpyHostToDevice) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "native tail: upload failed");
+  if (rc == MGS_OK) rc = mgs_vec_create(ctx, T->n_t, &T->b);
+  if (rc == MGS_OK) rc = mgs_vec_create(ctx, T->n_t, &T->x);
+  if (rc != MGS_OK) return fail(rc);
   return MGS_OK;
 }
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev) {
@@ -707,8 +718,24 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 //   c1 = B rhs, v1 = A c1, r' = rhs − (α1/ρ1) v1;  c2 = B r', v2 = A c2;
 //   x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1.
 static bool kcycle_here(const mgs_hier *h, int l) {
-  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && !h->halo && !h->halo_begin && !h->native && h->lev[l].kscal;
+  const bool sharded = h->halo || h->halo_begin || h->native;
+  // row shards: the five inner products are summed over the ranks — needs a reduction transport (native RCCL or the callback)
+  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && h->lev[l].kscal &&
+         (!sharded || h->ctx->ncomm || h->ctx->allreduce);
 }
+// sum of `cnt` device scalars over the ranks of a row-sharded run (no-op on one GPU)
+static int kc_allreduce(mgs_hier *h, double *dev, int cnt) {
+  mgs_ctx *ctx = h->ctx;
+  if (!(h->halo || h->halo_begin || h->native)) return MGS_OK;
+  if (ctx->ncomm) return mgs_comm_allreduce_sum(ctx->ncomm, dev, (size_t)cnt);
+  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, dev, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->allreduce(ctx->allreduce_user, ctx->red_host, cnt)) return mgs_fail(ctx, MGS_ERR_STATE, "all-reduce callback failed");
+  MGS_HIP(ctx, hipMemcpyAsync(dev, ctx->red_host, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));     // red_host is reused by the next reduction
+  return MGS_OK;
+}
+static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out);
 static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
   if (!kcycle_here(h, l)) return cycle_level(h, l, rhs, x, true);
   mgs_ctx *ctx = h->ctx;
@@ -716,15 +743,17 @@ static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
   const int n = L.n;
   double *sc = L.kscal;
   MGS_TRY(cycle_level(h, l, rhs, L.kc1->d, true));
-  MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_SPMV, L.kc1->d, nullptr, nullptr, 0.0, L.kv1->d));
+  MGS_TRY(sharded_op(h, l, L.A, MGS_OP_SPMV, L.kc1->d, nullptr, nullptr, 0.0, L.kv1->d));      // halo of c1 refreshed on a row shard
   MGS_TRY(k_dot_dev(ctx, n, L.kv1->d, L.kv1->d, sc + 0));
   MGS_TRY(k_dot_dev(ctx, n, L.kv1->d, rhs, sc + 1));
+  MGS_TRY(kc_allreduce(h, sc, 2));
   MGS_TRY(k_kc_update_r(ctx, n, sc, rhs, L.kv1->d, L.kr->d));
   MGS_TRY(cycle_level(h, l, L.kr->d, L.kc2->d, true));
-  MGS_TRY(mgs_launch_csr_op(L.A, MGS_OP_SPMV, L.kc2->d, nullptr, nullptr, 0.0, L.kv2->d));
+  MGS_TRY(sharded_op(h, l, L.A, MGS_OP_SPMV, L.kc2->d, nullptr, nullptr, 0.0, L.kv2->d));
   MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kv1->d, sc + 2));
   MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kv2->d, sc + 3));
   MGS_TRY(k_dot_dev(ctx, n, L.kv2->d, L.kr->d, sc + 4));
+  MGS_TRY(kc_allreduce(h, sc + 2, 3));
   return k_kc_combine(ctx, n, sc, L.kc1->d, L.kc2->d, x);
 }
 
@@ -934,8 +963,11 @@ static int prepare_fused(mgs_hier *h) {
         L.grp_tried = true; MGS_TRY(mgs_build_groups(ctx, L.A, L.T, &L.grp)); drop_graph(h);
       }
       // codes whose tuples depend on Â's values (or, on a shard, on the halo tags) follow val_wd
-      if (ctx->opt_rowcode && new_vals && (shard || ctx->opt_valcode)) {
+      if (new_vals && (L.code_pre || L.code_hat)) {     // whatever the options say NOW: a code built from the old Â must not survive it
         mgs_free_rowcode(L.code_pre); L.code_pre = nullptr; mgs_free_rowcode(L.code_hat); L.code_hat = nullptr; drop_graph(h);
+      }
+      if (ctx->opt_rowcode && new_vals && (shard || ctx->opt_valcode)) {
+        drop_graph(h);
         // on a shard the pre pass reads b (owned entries only) + the payload: halo columns need tagged table words
         if (shard) MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, L.A->rows, &L.code_pre, ctx->opt_valcode ? L.val_wd : nullptr));
         else MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.A->col, nullptr, 0x7fffffff, &L.code_hat, L.val_wd));

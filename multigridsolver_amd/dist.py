@@ -538,6 +538,15 @@ class ShardedHierarchy:
             self.tail.set_smoother(omega, nu1, nu2)
         return self
 
+    def set_kcycle(self, levels):
+        """K-cycle (two GCR steps per coarse solve) on the sharded levels 1..levels — inner products summed over the ranks — and, past
+        the last sharded level, on the replicated tail's own levels"""
+        self.install_allreduce()
+        self.h.set_kcycle(levels)
+        if self.tail:
+            self.tail.set_kcycle(max(0, levels - (len(self.plans) - 1)))
+        return self
+
     def vcycle(self, b, x, zero_guess=True):
         """b: owned entries; x: n_loc + n_halo entries (halo room behind the owned part)"""
         return self.h.vcycle(b, x, zero_guess)

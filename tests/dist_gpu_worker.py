@@ -103,6 +103,16 @@ def main():
     xr = ho.vcycle(bg)
     err = np.linalg.norm(x_loc - xr[lo * n2: hi * n2]) / np.linalg.norm(xr[lo * n2: hi * n2])
     assert err <= 1e-10, err
+    # K-cycle on the sharded levels: inner products summed over the ranks, against the oracle's K-cycle
+    kerr = None
+    if len(sh.plans) >= 3 and not mtx:
+        sh.set_kcycle(1); ho.set_kcycle(1)
+        xk = ctx.vec(n_ext); sh.vcycle(b, xk)
+        xkr = ho.vcycle(bg)
+        kerr = np.linalg.norm(xk.numpy(n_loc) - xkr[lo * n2: hi * n2]) / np.linalg.norm(xkr[lo * n2: hi * n2])
+        assert kerr <= 1e-9, kerr
+        assert np.linalg.norm(xk.numpy(n_loc) - x_loc) > 1e-6 * np.linalg.norm(x_loc), "K-cycle did not change the cycle"
+        sh.set_kcycle(0); ho.set_kcycle(0)
     # preconditioned solve across shards (dots all-reduced), true residual checked globally
     xsol = ctx.vec(n_ext)
     st, it, tol = sh.bicgstab(xsol, b, 300, 1e-10)
@@ -115,7 +125,7 @@ def main():
     dist.barrier()
     if rank == 0:
         ngrp = sum(1 for l in range(len(sh.plans) - 1) if sh.h.group_info(l)["groups"] > 0)
-        print(f"DIST_OK world={world} N={N} grouped_levels={ngrp} sharded_levels={len(sh.plans)} total_levels={sh.nlev} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
+        print(f"DIST_OK world={world} N={N} grouped_levels={ngrp} sharded_levels={len(sh.plans)} total_levels={sh.nlev} kcycle_err={kerr} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
     del sh, b, x, xs, y, xsol, A
     ctx.close()
     dist.destroy_process_group()

@@ -24,6 +24,21 @@ def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 700, 0), (3, 36, 500, 0), (2, 40, 700, 1)])
+def test_kcycle_on_row_shards(world, N, tail, native):
+    """K-cycle on sharded levels: the five inner products of the two GCR steps summed over the ranks (callback transport: host
+    all-reduce; native transport: ncclAllReduce of the stand-in) — one K-cycle application vs the oracle's K-cycle (≤1e-9)"""
+    fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if native:
+        env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    port = 29850 + (os.getpid() % 1000) + world + 10 * native
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout and "kcycle_err=" in r.stdout and "kcycle_err=None" not in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
 @pytest.mark.parametrize("world,N,tail,native", [(2, 40, 3000, 0), (3, 36, 2000, 0), (2, 40, 3000, 1), (3, 36, 2000, 1)])
 def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
     """the grouped pre pass (restriction inside the pre pass, t-form post pass) on row shards — halo payload exchanged first, halo-tagged

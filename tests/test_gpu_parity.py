@@ -177,6 +177,25 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
     assert rel(xg, ho.vcycle(b.numpy())) <= 1e-10
 
 
+def test_value_codes_do_not_survive_a_new_omega(ctx, mg):
+    """a hierarchy built with the opt-in value patterns, then valcode switched off and ω changed: the pre pass must not keep
+    running on tuples that carry the old A·diag(ωD⁻¹) values"""
+    A = ctx.poisson3d(32); n = 32 ** 3
+    b = ctx.vec(n).rand(seed=11)
+    try:
+        ctx.set_option("valcode", 1)
+        h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
+        h.vcycle(b)
+        ctx.set_option("valcode", 0)
+        h.set_smoother(0.8, 1, 1)
+        got = h.vcycle(b).numpy()
+    finally:
+        ctx.set_option("valcode", 0)
+    A2 = ctx.poisson3d(32)
+    h2 = mg.Hierarchy(A2, 0.8, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
+    assert rel(got, h2.vcycle(b).numpy()) <= 1e-13
+
+
 def test_vcycle_multilevel_vs_oracle(ctx, mg, orc, inputs):
     """3-level V(1,1)/V(2,1) cycle with reference-built P's, GPU vs CPU restatement."""
     Ao = orc.Csr.read(inputs["CSky3d30"]); P0o = orc.Csr.read(inputs["CSky3d30promatrix_cpu"])
