@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""same-process A/B of grouping variants of the grouped pre pass (option sets given as key=value,key=value strings; groups are
+built at a hierarchy's first cycle): alternating timed cycles, so box-to-box and run-to-run drift cancels.
+usage: ab_group2.py <grid> <optset1> <optset2> [...]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multigridsolver_amd as mg
+N = int(sys.argv[1]); sets = sys.argv[2:]
+ctx = mg.Context(0)
+A = ctx.poisson3d(N); n = N ** 3
+b = ctx.vec(n).rand(seed=0)
+hs = []
+for sset in sets:
+    for kv in sset.split(","):
+        k, v = kv.split("="); ctx.set_option(k, int(v))
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
+    x = ctx.vec(n)
+    for _ in range(3): h.vcycle(b, x)
+    hs.append((sset, h, x, [h.group_info(l) for l in range(2)]))
+res = {s: [] for s, *_ in hs}
+for rnd in range(5):
+    for sset, h, x, _ in hs:
+        for kv in sset.split(","):
+            k, v = kv.split("="); ctx.set_option(k, int(v))
+        h.vcycle(b, x)
+        res[sset].append(h.time_vcycle(b, x, reps=20))
+for sset, h, x, info in hs:
+    print(f"{sset:40s} min {min(res[sset]):.3f} med {sorted(res[sset])[2]:.3f} ms   L0 {info[0]}")

@@ -18,7 +18,7 @@ with open(os.path.join(REPO, "profiles", f"{tag}_bench_prof.md"), "w") as f:
     for k, v in sorted(byk.items()):
         f.write(f"| {k} | {len(v)} | {sum(v)/len(v)/1e3:.1f} | {min(v)/1e3:.1f} | {max(v)/1e3:.1f} |\n")
     f.write("\n`csr_rowblock_coded_kernel<0, ...>` = SpMV with the pattern-coded index (the roofline kernel; also launched twice per BiCGSTAB iteration), "
-            "`<1>` residual (= fused pre pass on the scaled values), `<2>` Jacobi, `<5>` fused post pass (template tail `<…, HALO, VAL>`: `VAL = true` rows belong to the opt-in value-pattern leg, not to the headline); `csr_rowblock_slice_kernel<0>` = plain CSR SpMV "
+            "`<1>` residual (= fused pre pass on the scaled values; in the cycle itself the fine level runs `csr_group_pre_kernel`: pre pass + restriction in one kernel), `<2>` Jacobi, `<5>` fused post pass (template tail `<…, HALO, VAL>`: `VAL = true` rows belong to the opt-in value-pattern leg, not to the headline); `csr_rowblock_slice_kernel<0>` = plain CSR SpMV "
             "(timed once for comparison, `rowcode` = 0), `csr_rowblock_fused_kernel<3>/<4>` = gather forms of the fused passes (unfused/A-B legs only).\n\nTop of the --stats table (all sizes mixed):\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))[:12]:
         nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
