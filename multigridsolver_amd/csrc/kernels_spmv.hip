@@ -1176,8 +1176,7 @@ int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_grou
     for (int b = 0; b < nblocks; ++b)
       for (int sl = 0; sl < GRP_SLOTS; ++sl) {
         const int k = hk[(size_t)b * GRP_SLOTS + sl], c = hn[(size_t)b * GRP_SLOTS + sl];
-        // only links that carry a real share of the block's aggregates: a handful of odd-shaped boundary aggregates must not drag
-        // row blocks of another plane into the group (measured: +15 % HBM traffic from lost x-plane reuse in L2) — they stay strays
+        // option group_min_link: only links that carry a share of the block's aggregates (default 1 = every link; see mgs_internal.hpp)
         if (k > b && k < nblocks && c >= ctx->opt_group_min_link) links.push_back({c, b, k});
       }
     std::sort(links.begin(), links.end(), [](const Link &p, const Link &q) { return p.cnt != q.cnt ? p.cnt > q.cnt : (p.a != q.a ? p.a < q.a : p.b < q.b); });

@@ -39,9 +39,10 @@ struct mgs_ctx {
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
   int opt_group_min_blocks = 1024;  // ... levels with fewer row blocks keep the separate kernels
-  int opt_group_min_link = 8;   // ... aggregates two row blocks must share to be grouped
-  int opt_group_blocks = 2;    // ... row blocks per group (1..4).  2: the residual buffer stays at 4 KB of LDS and 8 workgroups fit a CU — with 4-block
-                               // groups (8 KB, 7 workgroups) the same cycle measured 4.7 % slower although fewer aggregates strayed
+  int opt_group_min_link = 1;   // ... aggregates two row blocks must share to be grouped (8: keeps a few odd boundary aggregates from pulling blocks of
+                                // another plane into the group — 8 % less HBM traffic for that kernel, yet 2 % slower: fewer, fatter workgroups win)
+  int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/ab_group2.py): 4-block groups 6.21 ms per cycle,
+                               // pairs 6.34 ms, separate kernels 6.64 ms
   int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:

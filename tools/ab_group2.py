@@ -10,10 +10,17 @@ N = int(sys.argv[1]); sets = sys.argv[2:]
 ctx = mg.Context(0)
 A = ctx.poisson3d(N); n = N ** 3
 b = ctx.vec(n).rand(seed=0)
+DEFAULTS = "fuse_restrict=1,group_min_link=1,group_blocks=4,group_stray_pct=6"
+
+
+def apply(sset):
+    for kv in (DEFAULTS + "," + sset).split(","):      # every variant starts from the defaults (an option of the previous variant must not leak)
+        k, v = kv.split("="); ctx.set_option(k, int(v))
+
+
 hs = []
 for sset in sets:
-    for kv in sset.split(","):
-        k, v = kv.split("="); ctx.set_option(k, int(v))
+    apply(sset)
     h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
     x = ctx.vec(n)
     for _ in range(3): h.vcycle(b, x)
@@ -21,8 +28,7 @@ for sset in sets:
 res = {s: [] for s, *_ in hs}
 for rnd in range(5):
     for sset, h, x, _ in hs:
-        for kv in sset.split(","):
-            k, v = kv.split("="); ctx.set_option(k, int(v))
+        apply(sset)
         h.vcycle(b, x)
         res[sset].append(h.time_vcycle(b, x, reps=20))
 for sset, h, x, info in hs:
