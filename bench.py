@@ -167,7 +167,7 @@ def cpu_baseline(mg, args):
     ho = orc.Hier(As[0], Ps, omega=args.omega, nu1=args.nu1, nu2=args.nu2, As=As)
     ho.vcycle(b)  # warm-up
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 6.0:
+    while reps < 3 or time.perf_counter() - t0 < 12.0:
         x = ho.vcycle(b); reps += 1
     t_cycle = (time.perf_counter() - t0) / reps
     # parity of this very sample against the GPU cycle (cheap, keeps the baseline honest)
@@ -243,7 +243,7 @@ def parse_args():
     ap.add_argument("--npass", type=int, default=2)
     ap.add_argument("--tou", type=float, default=8.0)
     ap.add_argument("--coarse-rows", type=int, default=2500)
-    ap.add_argument("--cpu-grid", type=int, default=128)
+    ap.add_argument("--cpu-grid", type=int, default=256, help="grid of the CPU-baseline sample (oracle V-cycle, 1 thread): 256^3 = 1/8 of the rows of the headline grid")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
     return ap.parse_args()
