@@ -94,6 +94,20 @@ __global__ void gather_kernel(const double *__restrict__ x, const int *__restric
 }
 
 // setup-time operands of the fused cycle passes (unsharded levels): scaled values and aggregate-mapped columns
+// position of the diagonal entry inside its row (0..254; 255 = absent or further in): the t-form post pass reads a_ii from there
+__global__ void diag_pos_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, unsigned char *__restrict__ dpos) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = rowptr[i];
+  int lo = a, hi = rowptr[i + 1] - 1, pos = 255;
+  while (lo <= hi) {
+    int mid = lo + ((hi - lo) >> 1);
+    int c = col[mid];
+    if (c == i) { pos = mid - a < 255 ? mid - a : 255; break; }
+    if (c < i) lo = mid + 1; else hi = mid - 1;
+  }
+  dpos[i] = (unsigned char)pos;
+}
 __global__ void scale_vals_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
                                   const double *__restrict__ wd, double *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -386,6 +400,12 @@ int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host) {
   return MGS_OK;
 }
 
+int k_diag_pos(const mgs_csr *A, unsigned char *dpos) {
+  mgs_ctx *ctx = A->ctx;
+  if (A->rows) hipLaunchKernelGGL(diag_pos_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, dpos);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc) {
   if (nc) hipLaunchKernelGGL(restrict_agg_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, r, rc);
   MGS_HIP(ctx, hipGetLastError());

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
     const double *__restrict__ x /*gather source: x, or e_c for the post pass*/, const double *__restrict__ b /*b, or r for the post pass*/,
     const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
     const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,
-    const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab) {
+    const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab,
+    const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int vb = map_block(bm, blockIdx.x);
@@ -377,11 +378,17 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
   const bool staged = hi - lo <= capv && (coded || nent + 1 <= capi_abs);     // block-uniform
   int ga = 0, ge = 0, base = row;
   double bi = 0.0, di = 0.0, xi = 0.0, pei = 0.0;
+  const bool dmode = POST && dpos != nullptr && xin == nullptr;    // ωD⁻¹ from the streamed diagonal entry (same bits as wd = ω·(1/a_ii))
+  unsigned dp = 255;
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
     if (OP != MGS_OP_SPMV) bi = b[row];
     if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
-    if (POST) { di = dinv[row]; xi = xin ? di * xin[row] : 0.0; base = agg[row]; pei = base >= 0 ? x[base] : 0.0; }   // xin = NULL: b holds t = b + r
+    if (POST) {                                                     // xin = NULL: b holds t = b + r
+      if (dmode) dp = dpos[row];
+      if (!dmode || dp == 255) di = dinv[row];
+      xi = xin ? di * xin[row] : 0.0; base = agg[row]; pei = base >= 0 ? x[base] : 0.0;
+    }
   }
   double s = 0.0;
   if (staged) {
@@ -421,6 +428,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
 #pragma unroll
           for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
         }
+        if (POST && dmode && dp != 255) di = omega * (1.0 / (VAL ? vals[ps + (int)dp] : vals[my_a + (int)dp]));
       } else {
         for (int k = my_a; k < my_e; k += U) {
           int cq[U]; double xv[U], vq[U];
@@ -436,6 +444,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
 #pragma unroll
           for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
         }
+        if (POST && dmode && dp != 255) di = omega * (1.0 / vals[my_a + (int)dp]);
       }
     }
   } else if (row < r1) {
@@ -444,6 +453,7 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
       const int c = idx[k];
       s += val[k] * ((HALO && c >= split) ? hv[c - split] : ((POST && c < 0) ? 0.0 : x[c]));
     }
+    if (POST && dmode && dp != 255) di = omega * (1.0 / val[ga + (int)dp]);
   }
   if (row < r1) {
     double v;
@@ -1114,7 +1124,8 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
-                                           c->pid, c->tptr, c->tab, x, b, dinv, omega, xin, agg, out, capv, ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab)
+                                           c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
+                                           ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr)
 #define CH_(O, UU) do { if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
                         else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
 #define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)

@@ -132,6 +132,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "split_min_rows") ctx->opt_split_min_rows = value;
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else if (k == "fuse_restrict") ctx->opt_fuse_restrict = value;
+  else if (k == "diag_from_values") ctx->opt_diag_from_values = value;
   else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "group_min_link") ctx->opt_group_min_link = value;
@@ -399,6 +400,7 @@ static void level_free(mgs_level &L) {
   mgs_free_rowcode(L.code_pre);
   mgs_free_rowcode(L.code_hat);
   mgs_free_groups(L.grp);
+  if (L.dpos) hipFree(L.dpos);
   if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
   if (L.kscal) hipFree(L.kscal);
@@ -840,6 +842,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     mgs_csr Ahat = *L.A; Ahat.val = L.val_wd; Ahat.owns = false;
     Ahat.code = halo ? L.code_pre : ((L.A->code && L.A->code->vtab) || L.code_hat ? L.code_hat : L.A->code);
     mgs_csr Amap = *L.A; Amap.val = L.A->val; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
+    if (ctx->opt_diag_from_values && L.dpos) { Amap.dpos = L.dpos; Amap.dpos_omega = h->omega; }   // t-form post pass: ω/a_ii from the streamed values
     const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
                           (!halo || (mgs_rowcode_usable(&Ahat, true) && mgs_rowcode_usable(&Amap, true)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
@@ -959,6 +962,9 @@ static int prepare_fused(mgs_hier *h) {
         if (ctx->opt_rowcode)
           MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg,
                                     ctx->opt_valcode ? L.A->val : nullptr));
+      }
+      if (ctx->opt_diag_from_values && !L.dpos) {
+        MGS_TRY(mgs_dev_alloc(ctx, &L.dpos, (size_t)L.A->rows)); MGS_TRY(k_diag_pos(L.A, L.dpos)); drop_graph(h);
       }
       if (ctx->opt_fuse_restrict && !L.grp_tried) {   // row-block groups of the grouped pre pass (null: level does not qualify)
         L.grp_tried = true; MGS_TRY(mgs_build_groups(ctx, L.A, L.T, &L.grp)); drop_graph(h);

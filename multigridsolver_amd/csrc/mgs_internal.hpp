@@ -37,6 +37,7 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
   int opt_group_min_blocks = 1024;  // ... levels with fewer row blocks keep the separate kernels
   int opt_group_min_link = 1;   // ... aggregates two row blocks must share to be grouped (8: keeps a few odd boundary aggregates from pulling blocks of
@@ -85,6 +86,8 @@ struct mgs_csr {
   int max_wave_nnz = 0;   // max entries of a 64-row group
   mgs_rowcode *code = nullptr;   // pattern code of col (mgs_csr_optimize; owned unless this is a view)
   bool code_tried = false;
+  const unsigned char *dpos = nullptr;   // views of the t-form post pass only (not owned): position of the diagonal inside every row, so the
+  double dpos_omega = 0.0;               // kernel takes ω/a_ii from the values it streams anyway instead of reading wd (8 B → 1 B per row)
   int *origin = nullptr;   // coarse operators built by the device setup: the finest-level row each row descends from (its aggregate's
                            // leader, chained through the levels) — the index space the matching's tie-breaks work in; NULL = identity
 };
@@ -163,6 +166,7 @@ struct mgs_level {
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
   mgs_rowcode *code_pre = nullptr;   // row shards: pattern code of col with tagged halo words (pre pass reads b + payload)
   mgs_rowcode *code_hat = nullptr;   // option valcode: pattern code of (col, val_wd) for the pre pass on Â
+  unsigned char *dpos = nullptr;     // position of the diagonal entry inside each row (255: none / beyond 254), see mgs_csr::dpos
   mgs_groups *grp = nullptr;         // aggregate-complete row-block groups (grouped pre pass = pre pass + restriction in one kernel)
   bool grp_tried = false;
   mgs_vec *kc1 = nullptr, *kv1 = nullptr, *kc2 = nullptr, *kv2 = nullptr, *kr = nullptr;   // K-cycle work vectors
@@ -266,6 +270,7 @@ int mgs_launch_group_pre(const mgs_csr *Ahat, const mgs_groups *G, const mgs_xfe
                          double *t_out, double *r_out, double *rc_out, const double *hv, int split);
 // (kernels_aux.hip)
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
+int k_diag_pos(const mgs_csr *A, unsigned char *dpos);
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc);
 int k_prolong_agg(mgs_ctx *ctx, int n, const int *agg, const double *ec, double *x, int add);
 int k_fill(mgs_ctx *ctx, double *d, int64_t n, double v);

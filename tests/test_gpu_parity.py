@@ -159,6 +159,9 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
         ctx.set_option("group_min_blocks", 1)
         ctx.set_option("fuse_restrict", 1); xg = h.vcycle(b).numpy()
         info = [h.group_info(l) for l in range(h.nlev - 1)]
+        ctx.set_option("diag_from_values", 0); xw = h.vcycle(b).numpy()      # t-form post pass reading the wd vector instead of a_ii
+        ctx.set_option("diag_from_values", 1)
+        assert np.array_equal(xg, xw)                                          # ω·(1/a_ii) either way: same bits
         ctx.set_option("fuse_restrict", 0); xs = h.vcycle(b).numpy()
     finally:
         ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6); ctx.set_option("group_min_blocks", 1024)
