@@ -141,7 +141,7 @@ def test_bundled_operators_vs_reference_golden(ctx, mg, orc, inputs, golden, nam
     assert st == 0 and np.linalg.norm(Ao.residual(xs.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.5e-10, (st, it, tol)
 
 
-@pytest.mark.parametrize("kind", ["poisson3d_64", "poisson3d_40", "poisson3d_33", "poisson2d_130", "CSky3d30", "CSky2d100"])
+@pytest.mark.parametrize("kind", ["poisson3d_64", "poisson3d_40", "poisson3d_33", "poisson2d_130", "CSky3d30", "CSky2d100", "random_graph"])
 def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
     """option fuse_restrict (default on): pre pass + restriction in one kernel over aggregate-complete row-block groups, post pass in its
     t-form — against the separate kernels (≤1e-13: only the post pass's rounding differs) and against the oracle's cycle (≤1e-10)"""
@@ -149,13 +149,24 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
         A = ctx.poisson3d(int(kind.split("_")[1]))
     elif kind.startswith("poisson2d"):
         A = ctx.poisson2d(int(kind.split("_")[1]))
+    elif kind == "random_graph":           # shifted Laplacian of a random graph with local + a few far edges: aggregates of arbitrary shape, many strays
+        import scipy.sparse as sps
+        rng = np.random.default_rng(12)
+        m = 30000
+        i = np.concatenate([np.arange(m - 1), rng.integers(0, m, 2 * m), rng.integers(0, m, m // 20)])
+        j = np.concatenate([np.arange(1, m), np.clip(i[m - 1:3 * m - 1] + rng.integers(-40, 41, 2 * m), 0, m - 1), rng.integers(0, m, m // 20)])
+        keep = i != j
+        W = sps.coo_matrix((rng.uniform(0.5, 1.5, keep.sum()), (i[keep], j[keep])), shape=(m, m)).tocsr()
+        W = W + W.T
+        M = (sps.diags(np.asarray(W.sum(axis=1)).ravel() + 0.02) - W).tocsr(); M.sort_indices()
+        A = ctx.csr(m, m, M.indptr, M.indices, M.data)
     else:
         A = mg.Csr.from_mtx(ctx, inputs[kind])
     n = A.shape[0]
     h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
     b = ctx.vec(n).rand(seed=3)
     try:
-        ctx.set_option("group_stray_pct", 60)                # small grids: many aggregates leave their group — exercise that path too
+        ctx.set_option("group_stray_pct", 100 if kind == "random_graph" else 60)   # small grids: many aggregates leave their group — exercise that path too
         ctx.set_option("group_min_blocks", 1)
         ctx.set_option("fuse_restrict", 1); xg = h.vcycle(b).numpy()
         info = [h.group_info(l) for l in range(h.nlev - 1)]
