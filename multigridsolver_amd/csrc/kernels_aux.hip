@@ -487,6 +487,40 @@ int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out
   return MGS_OK;
 }
 
+// middle stage for long partial arrays (one pair per row block of a 512³ operator = 2 × 524 288): workgroup g sums the g-th
+// contiguous chunk of each array in a fixed order
+__global__ __launch_bounds__(TB) void dot2_mid_kernel(int nb, int chunk, const double *__restrict__ part, double *__restrict__ out /*[2][gridDim.x]*/) {
+  __shared__ double sh[2][TB / 64];
+  const int lo = blockIdx.x * chunk, hi = min(lo + chunk, nb);
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += TB) { s0 += part[i]; s1 += part[nb + i]; }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    out[blockIdx.x] = t0; out[gridDim.x + blockIdx.x] = t1;
+  }
+}
+int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part, double *out_host2) {
+  if (nb > 4096) {          // three stages: row-block partials → 256 chunk sums (in red_dev) → the pair
+    const int groups = DOT_BLOCKS / 4, chunk = (nb + groups - 1) / groups;
+    hipLaunchKernelGGL(dot2_mid_kernel, dim3(groups), dim3(TB), 0, ctx->stream, nb, chunk, part, ctx->red_dev);
+    part = ctx->red_dev; nb = groups;
+  }
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, part, ctx->red_dev + DOT_BLOCKS);
+  MGS_HIP(ctx, hipGetLastError());
+  if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
+  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
+  if (ctx->allreduce && !ctx->ncomm) {
+    int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
+    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
+  }
+  return MGS_OK;
+}
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2) {
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;

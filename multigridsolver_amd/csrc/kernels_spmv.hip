@@ -357,7 +357,9 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
     const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
     const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,
     const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab,
-    const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/) {
+    const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/,
+    const double *__restrict__ dot_w1, double *__restrict__ dot_part /*SpMV: (y·w1, y·y) partials [2][nblocks] of this launch (NULL: none)*/,
+    int dot_nb) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int vb = map_block(bm, blockIdx.x);
@@ -462,6 +464,19 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
     else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
     else v = xin ? (xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
     if (capi < 0) __builtin_nontemporal_store(v, out + row); else out[row] = v;   // capi < 0: streaming store (A/B option nt_store)
+    if (OP == MGS_OP_SPMV && dot_part) { bi = v * dot_w1[row]; di = v * v; }       // this row's terms of (y·w1, y·y); bi/di are free in this op
+  }
+  if (OP == MGS_OP_SPMV && dot_part) {      // launch-uniform: one partial pair per row block, summed in a fixed order
+    double p1 = row < r1 ? bi : 0.0, p2 = row < r1 ? di : 0.0;
+    for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_down(p1, off); p2 += __shfl_down(p2, off); }
+    __syncthreads();                                   // the staged values are done with: their LDS holds the 4 wave sums
+    if ((tid & 63) == 0) { vals[2 * (tid >> 6)] = p1; vals[2 * (tid >> 6) + 1] = p2; }
+    __syncthreads();
+    if (tid == 0) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int q = 0; q < RB / 64; ++q) { t1 += vals[2 * q]; t2 += vals[2 * q + 1]; }
+      dot_part[blk] = t1; dot_part[dot_nb + blk] = t2;
+    }
   }
 }
 
@@ -1125,7 +1140,8 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                            c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
-                                           ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr)
+                                           ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
+                                           O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB)
 #define CH_(O, UU) do { if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
                         else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
 #define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)
@@ -1300,6 +1316,24 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
     MGS_HIP(ctx, hipGetLastError());
   }
   return MGS_OK;
+}
+
+int mgs_spmv_dots(const mgs_csr *A, const double *x, double *y, const double *w1, double *out_host2) {
+  mgs_ctx *ctx = A->ctx;
+  const int nb = (A->rows + RB - 1) / RB;
+  const bool fused = ctx->opt_fuse_dots && A->rows > 0 && ctx->opt_spmv_variant == 0 && !ctx->opt_nontemporal && use_rowcode(A, A->code) && A->lds_cap >= 8;
+  if (!fused) {
+    MGS_TRY(mgs_launch_csr_op(A, MGS_OP_SPMV, x, nullptr, nullptr, 0.0, y));
+    return k_dot2(ctx, A->rows, y, w1, y, y, out_host2);
+  }
+  if (ctx->dot_part_cap < 2 * (int64_t)nb) {
+    if (ctx->dot_part) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dot_part); ctx->dot_part = nullptr; }
+    MGS_TRY(mgs_dev_alloc(ctx, &ctx->dot_part, (size_t)2 * nb));
+    ctx->dot_part_cap = 2 * (int64_t)nb;
+  }
+  mgs_csr V = *A; V.owns = false; V.dot_w1 = w1; V.dot_part = ctx->dot_part;     // every row block of the launch writes its pair
+  MGS_TRY(mgs_launch_csr_op(&V, MGS_OP_SPMV, x, nullptr, nullptr, 0.0, y));
+  return k_dot2_finish(ctx, nb, ctx->dot_part, out_host2);
 }
 
 bool mgs_rowcode_usable(const mgs_csr *A, bool any) { return use_rowcode(A, A->code, any); }

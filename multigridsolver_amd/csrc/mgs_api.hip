@@ -107,6 +107,7 @@ int mgs_ctx_destroy(mgs_ctx *c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   if (c->red_dev) hipFree(c->red_dev);
+  if (c->dot_part) hipFree(c->dot_part);
   if (c->red_host) hipHostFree(c->red_host);
   if (c->own_stream) hipStreamDestroy(c->stream);
   if (c->comm_stream) hipStreamDestroy(c->comm_stream);
@@ -133,6 +134,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "blkptr") ctx->opt_blkptr = value;
   else if (k == "fuse_restrict") ctx->opt_fuse_restrict = value;
   else if (k == "diag_from_values") ctx->opt_diag_from_values = value;
+  else if (k == "fuse_dots") ctx->opt_fuse_dots = value;
   else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "group_min_link") ctx->opt_group_min_link = value;
@@ -1105,8 +1107,7 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     }
     MGS_TRY(precond(p, phat));                                                        // :106
     if (halo0(phat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
-    MGS_TRY(mgs_spmv(A, phat, v));                                                    // :107
-    MGS_TRY(mgs_dot(rt, v, &tmp)); alpha = rho_1 / tmp;                               // :108
+    MGS_TRY(mgs_spmv_dots(A, phat->d, v->d, rt->d, d2)); alpha = rho_1 / d2[0];      // :107-108  v = A·p̂ with r̃·v from the same pass
     MGS_TRY(k_update_dot2(ctx, n, 1.0, r->d, -alpha, v->d, s->d, nullptr, d2));      // :109 s = r − αv, with ‖s‖² in the same pass
     tmp = std::sqrt(d2[0]);
     if ((resid = tmp / normb) < *tol) {                                               // :110-115
@@ -1115,8 +1116,7 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
     }
     MGS_TRY(precond(s, shat));                                                        // :116
     if (halo0(shat)) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange failed");
-    MGS_TRY(mgs_spmv(A, shat, t));                                                    // :117
-    MGS_TRY(k_dot2(ctx, n, t->d, s->d, t->d, t->d, d2)); omega = d2[0] / d2[1];       // :118 (t·s, t·t)
+    MGS_TRY(mgs_spmv_dots(A, shat->d, t->d, s->d, d2)); omega = d2[0] / d2[1];       // :117-118  t = A·ŝ with (t·s, t·t) from the same pass
     MGS_TRY(mgs_axpbypcz(alpha, &phv, omega, &shv, 1.0, &xv));                        // :119
     MGS_TRY(k_update_dot2(ctx, n, 1.0, s->d, -omega, t->d, r->d, rt->d, d2));       // :120 r = s − ωt with ‖r‖² (:123) and the next (r̃,r) (:95)
     rho_2 = rho_1;                                                                    // :122

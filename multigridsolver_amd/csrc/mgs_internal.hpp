@@ -18,6 +18,7 @@ struct mgs_ctx {
   bool own_stream = false;
   std::string err;
   // scratch for reductions (device partials + pinned host landing zone)
+  double *dot_part = nullptr; int64_t dot_part_cap = 0;   // per-row-block partials of the dots fused into the SpMV epilogue
   double *red_dev = nullptr;
   double *red_host = nullptr;
   int red_cap = 0;
@@ -37,6 +38,7 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_fuse_dots = 1;         // BiCGSTAB: r̃·v and (t·s, t·t) in the epilogue of the SpMV that produces v resp. t
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
   int opt_group_min_blocks = 1024;  // ... levels with fewer row blocks keep the separate kernels
@@ -86,6 +88,8 @@ struct mgs_csr {
   int max_wave_nnz = 0;   // max entries of a 64-row group
   mgs_rowcode *code = nullptr;   // pattern code of col (mgs_csr_optimize; owned unless this is a view)
   bool code_tried = false;
+  // views made by mgs_spmv_dots only: (y·w1, y·y) of the product y = A·x accumulated in the SpMV's epilogue (one partial pair per row block)
+  const double *dot_w1 = nullptr; double *dot_part = nullptr;
   const unsigned char *dpos = nullptr;   // views of the t-form post pass only (not owned): position of the diagonal inside every row, so the
   double dpos_omega = 0.0;               // kernel takes ω/a_ii from the values it streams anyway instead of reading wd (8 B → 1 B per row)
   int *origin = nullptr;   // coarse operators built by the device setup: the finest-level row each row descends from (its aggregate's
@@ -282,6 +286,10 @@ int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *
 int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev);
 int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2);
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2);
+int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part /*[2][nb]*/, double *out_host2);   // second stage + rank reduction + host copy
+// y = A·x with (y·w1, y·y) from the same pass where the pattern-coded kernel serves A (else SpMV + k_dot2): BiCGSTAB's
+// v = A·p̂ with r̃·v (bicg.cpp:107-108) and t = A·ŝ with (t·s, t·t) (bicg.cpp:117-118)
+int mgs_spmv_dots(const mgs_csr *A, const double *x, double *y, const double *w1, double *out_host2);
 int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp);
 int k_kc_combine(mgs_ctx *ctx, int n, const double *scal, const double *c1, const double *c2, double *x);
 int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out);
