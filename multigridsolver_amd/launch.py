@@ -56,7 +56,7 @@ class Watchdog:
     """worker side: `beat(phase)` at every milestone; no beat for `limit` seconds → diagnostic + os._exit(77)"""
 
     def __init__(self, limit=None, out=sys.stderr):
-        self.limit = float(os.environ.get("MGS_BENCH_WATCHDOG_S", "240")) if limit is None else float(limit)
+        self.limit = float(os.environ.get("MGS_BENCH_WATCHDOG_S", "150")) if limit is None else float(limit)
         self.phase, self.t, self.out, self._stop = "start", time.monotonic(), out, False
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
