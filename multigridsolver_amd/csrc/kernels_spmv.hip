@@ -892,6 +892,113 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
 #undef GSEL
 }
 
+// Concurrent form for groups of at most two row blocks: a 512-thread workgroup, each half sweeps one block of the pair at the same
+// time (own value/table slices in LDS), one barrier later all 512 threads restrict the group's aggregates.  Same phase structure as the
+// plain row-block kernel plus one barrier (the sequential form above pays a second staging phase per extra block), same occupancy
+// (2 × slice + 4 KB of LDS per workgroup → 4 workgroups = 32 waves per CU).  Every barrier sits outside the per-block branches.
+template <int U, bool HALO>
+__global__ __launch_bounds__(2 * RB) void csr_group2_pre_kernel(
+    int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
+    const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
+    const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
+    double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split) {
+  extern __shared__ double lds_raw[];
+  const int g = map_block(bm, blockIdx.x);
+  if (g < 0) return;
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & (RB - 1);
+  const int half_doubles = capv + 2 + (capi + 1) / 2;
+  double *__restrict__ vals = lds_raw + half * half_doubles;
+  int *__restrict__ ints = reinterpret_cast<int *>(vals + capv + 2);
+  double *__restrict__ rbuf = lds_raw + 2 * half_doubles;                 // 2·RB residuals: block 0 of the pair, then block 1
+  const int4_t *__restrict__ gd = reinterpret_cast<const int4_t *>(gdesc + (size_t)GRP_DESC * g);
+  const int4_t gb = gd[0], glo = gd[1], ghi = gd[2], galo = gd[3], gahi = gd[4];
+  const int blk = half ? gb.y : gb.x;                                      // −1: a single-block group, this half only helps to restrict
+  const int a0 = (half ? galo.y : galo.x) + tid, ae = half ? gahi.y : gahi.x;
+  const unsigned long long code0 = (blk >= 0 && a0 < ae) ? acode[a0] : 0ull;
+  const int r0 = blk * RB, r1 = blk >= 0 ? min(r0 + RB, n) : 0;
+  const int lo = half ? glo.y : glo.x, hi = half ? ghi.y : ghi.x;
+  const int t0 = (tptr && blk >= 0) ? tptr[blk] : 0, tlen = (tptr && blk >= 0) ? tptr[blk + 1] - t0 : 0;
+  const int row = r0 + tid, start = lo & ~1, nent = hi - start;
+  const bool coded = tlen > 0 && tlen <= capi;
+  const bool staged = blk >= 0 && hi - lo <= capv && (coded || nent + 1 <= capi);   // uniform per half
+  int ga = 0, ge = 0;
+  double bi = 0.0;
+  unsigned wm = 0u;
+  if (blk >= 0 && row < r1) { ga = rowptr[row]; ge = rowptr[row + 1]; bi = b[row]; wm = wmask[row >> 5]; }
+  if (staged) {
+    const int nch = (nent + 1) >> 1;
+    if (coded) {
+#pragma unroll 4
+      for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+      for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
+    } else {
+#pragma unroll 4
+      for (int c = tid; c < nch; c += RB) {
+        const int k = start + 2 * c;
+        *reinterpret_cast<int2_t *>(ints + 2 * c) = *reinterpret_cast<const int2_t *>(idx + k);
+        *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + k);
+      }
+    }
+  }
+  __syncthreads();
+  double s = 0.0;
+  if (blk >= 0 && row < r1) {
+    if (staged) {
+      if (ge > ga) {
+        const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
+        if (coded) {
+          const int ps = ints[pid[row]];
+          const int last = my_e - my_a - 1;
+          for (int k = my_a, j = 0; k < my_e; k += U, j += U) {
+            int oq[U]; double xv[U], vq[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) oq[q] = ints[ps + min(j + q, last)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+              if (HALO && oq[q] >= CODE_HALO_LO) xv[q] = hv[row + (oq[q] - CODE_HALO)];
+              else xv[q] = x[row + oq[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+          }
+        } else {
+          for (int k = my_a; k < my_e; k += U) {
+            int cq[U]; double xv[U], vq[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) cq[q] = ints[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) xv[q] = (HALO && cq[q] >= split) ? hv[cq[q] - split] : x[cq[q]];
+#pragma unroll
+            for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
+#pragma unroll
+            for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
+          }
+        }
+      }
+    } else {
+      for (int k = ga; k < ge; ++k) { const int c = idx[k]; s += val[k] * ((HALO && c >= split) ? hv[c - split] : x[c]); }
+    }
+    const double r = bi - s;
+    t_out[row] = bi + r;
+    rbuf[half * RB + tid] = r;
+    if ((wm >> (row & 31)) & 1u) r_out[row] = r;                          // member of a stray aggregate
+  }
+  __syncthreads();
+  for (int a = a0; a < ae; a += RB) {                                      // this half's block's aggregates; positions span both halves
+    const unsigned long long code = a == a0 ? code0 : acode[a];
+    const int cnt = (int)(code & 15ull);
+    if (cnt == 0) continue;
+    int pos = (int)((code >> 4) & 1023ull), sh = 14;
+    double sum = 0.0;
+    sum += rbuf[pos];
+    for (int k = 1; k < cnt; ++k, sh += 10) { pos += (int)((code >> sh) & 1023ull); sum += rbuf[pos]; }
+    rc_out[a] = sum;
+  }
+}
+
 // number of row blocks whose entry count exceeds each of 4 candidate LDS budgets
 __global__ void plan_count_kernel(int n, const int *__restrict__ rowptr, int nblocks, int c0, int c1, int c2, int c3, int *__restrict__ out) {
   int vb = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1303,13 +1410,19 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
   const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
+  const bool pairs = G->max_blocks <= 2 && ctx->opt_group_concurrent;     // 512 threads, both blocks of a pair at once
+  const size_t lds2 = (size_t)2 * ((size_t)(capv + 2) * 8 + (size_t)((capi + 1) / 2) * 8) + (size_t)2 * RB * 8 + 16 + (size_t)ctx->opt_lds_pad;
+#define G2_(UU, H) hipLaunchKernelGGL((csr_group2_pre_kernel<UU, H>), grid, dim3(2 * RB), lds2, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
+                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
+                                      G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
 #define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
                                      G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
-#define GU_(UU) do { if (hv) G_(UU, true); else G_(UU, false); } while (0)
+#define GU_(UU) do { if (pairs) { if (hv) G2_(UU, true); else G2_(UU, false); } else { if (hv) G_(UU, true); else G_(UU, false); } } while (0)
   if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
 #undef GU_
 #undef G_
+#undef G2_
   MGS_HIP(ctx, hipGetLastError());
   if (G->nstray) {
     hipLaunchKernelGGL(restrict_stray_kernel, dim3((G->nstray + RB - 1) / RB), dim3(RB), 0, ctx->stream, G->nstray, G->stray, T->cptr, T->members, r_out, rc_out);

@@ -42,6 +42,8 @@ struct mgs_ctx {
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
   int opt_group_min_blocks = 1024;  // ... levels with fewer row blocks keep the separate kernels
+  int opt_group_concurrent = 0;  // groups of ≤ 2 blocks: 512-thread workgroups sweep both blocks at once (csr_group2_pre_kernel; same bits; measured at 512³:
+                                 // 6.59 ms per cycle against 6.50 for the sequential sweep of the same pairs and 6.13 for 4-block groups — kept for A/B)
   int opt_group_min_link = 1;   // ... aggregates two row blocks must share to be grouped (8: keeps a few odd boundary aggregates from pulling blocks of
                                 // another plane into the group — 8 % less HBM traffic for that kernel, yet 2 % slower: fewer, fatter workgroups win)
   int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/ab_group2.py): 4-block groups 6.21 ms per cycle,

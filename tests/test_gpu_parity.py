@@ -174,8 +174,16 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
         ctx.set_option("diag_from_values", 1)
         assert np.array_equal(xg, xw)                                          # ω·(1/a_ii) either way: same bits
         ctx.set_option("fuse_restrict", 0); xs = h.vcycle(b).numpy()
+        # groups of at most two row blocks run the concurrent 512-thread form (csr_group2_pre_kernel): its own hierarchy (groups are built once)
+        ctx.set_option("fuse_restrict", 1); ctx.set_option("group_blocks", 2); ctx.set_option("group_concurrent", 1)
+        h2 = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
+        x2 = h2.vcycle(b).numpy()
+        assert h2.group_info(0)["groups"] > 0 and rel(x2, xs) <= 1e-13, (rel(x2, xs), h2.group_info(0))
+        ctx.set_option("group_concurrent", 0)
+        assert np.array_equal(h2.vcycle(b).numpy(), x2)                        # sequential form over the same pairs: same bits
     finally:
         ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6); ctx.set_option("group_min_blocks", 1024)
+        ctx.set_option("group_blocks", 4); ctx.set_option("group_concurrent", 0)
     assert info[0]["groups"] > 0, info                      # the device matching numbers aggregates by their leader: level 0 qualifies
     assert rel(xg, xs) <= 1e-13, (rel(xg, xs), info)
     # oracle cycle on the downloaded hierarchy
