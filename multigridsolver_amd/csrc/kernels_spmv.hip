@@ -349,22 +349,21 @@ constexpr int CODE_HALO = 0x60000000, CODE_HALO_LO = 0x50000000, CODE_OFF_MAX = 
 
 // (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
 // VAL: the tuples carry the values as well (`vtab`, option valcode): a coded block then streams no matrix entry at all.
+// one 256-row block of the pattern-coded kernel (the two __global__ wrappers below call it once per workgroup, or once per row block
+// of a group of blocks)
 template <int OP, int U, bool HALO, bool VAL>
-__global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblock_coded_kernel(
-    int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
+__device__ __forceinline__ void coded_block_body(
+    const int blk, int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x /*gather source: x, or e_c for the post pass*/, const double *__restrict__ b /*b, or r for the post pass*/,
     const double *__restrict__ dinv /*dinv, or wd for the post pass*/, double omega, const double *__restrict__ xin /*post pass: b*/,
-    const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,
+    const int *__restrict__ agg /*post pass*/, double *__restrict__ out, int capv, int capi, const int *__restrict__ blkptr,
     const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab,
     const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/,
     const double *__restrict__ dot_w1, double *__restrict__ dot_part /*SpMV: (y·w1, y·y) partials [2][nblocks] of this launch (NULL: none)*/,
     int dot_nb) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
-  const int vb = map_block(bm, blockIdx.x);
-  if (vb < 0) return;
-  const int blk = block_of(bm, vb);
   const int r0 = blk * RB;
   const int r1 = min(r0 + RB, n);
   const int tid = threadIdx.x;
@@ -477,6 +476,38 @@ __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblo
       for (int q = 0; q < RB / 64; ++q) { t1 += vals[2 * q]; t2 += vals[2 * q + 1]; }
       dot_part[blk] = t1; dot_part[dot_nb + blk] = t2;
     }
+  }
+}
+
+#define CODED_PARAMS                                                                                                                    \
+    int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,                                  \
+    const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab, const double *__restrict__ x,      \
+    const double *__restrict__ b, const double *__restrict__ dinv, double omega, const double *__restrict__ xin,                         \
+    const int *__restrict__ agg, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,               \
+    const double *__restrict__ hv, int split, const double *__restrict__ vtab, const unsigned char *__restrict__ dpos,                   \
+    const double *__restrict__ dot_w1, double *__restrict__ dot_part, int dot_nb
+#define CODED_ARGS n, rowptr, idx, val, pid, tptr, tab, x, b, dinv, omega, xin, agg, out, capv, capi, blkptr, hv, split, vtab, dpos, dot_w1, dot_part, dot_nb
+
+// (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
+template <int OP, int U, bool HALO, bool VAL>
+__global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblock_coded_kernel(CODED_PARAMS) {
+  const int vb = map_block(bm, blockIdx.x);
+  if (vb < 0) return;
+  coded_block_body<OP, U, HALO, VAL>(block_of(bm, vb), CODED_ARGS);
+}
+// the same row blocks swept group by group (descriptors of the grouped pre pass: up to GRP_BLOCKS blocks per workgroup, one after the
+// other) — experiment: does the post pass gain what the grouped pre pass gains from fewer, fatter workgroups?
+template <int OP, int U, bool HALO, bool VAL>
+__global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblock_coded_group_kernel(CODED_PARAMS, const int *__restrict__ gdesc) {
+  const int g = map_block(bm, blockIdx.x);
+  if (g < 0) return;
+  const int4_t gb = *reinterpret_cast<const int4_t *>(gdesc + (size_t)32 * g);
+#pragma unroll 1
+  for (int h = 0; h < 4; ++h) {
+    const int blk = h == 0 ? gb.x : (h == 1 ? gb.y : (h == 2 ? gb.z : gb.w));
+    if (blk < 0) break;                               // group-uniform
+    if (h) __syncthreads();                           // the previous block's LDS slice is done with
+    coded_block_body<OP, U, HALO, VAL>(blk, CODED_ARGS);
   }
 }
 
@@ -1233,6 +1264,7 @@ static bool use_rowcode(const mgs_csr *A, const mgs_rowcode *c, bool any = false
          (any || (double)c->coded_blocks >= 0.5 * c->nblocks);
 }
 // op ∈ {SPMV, RESIDUAL, JACOBI, FUSE_POST_MAPPED}; for the post pass: x = e_c, b = r, dinv = wd, xin = b, idx = agg[col]
+static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm);
 static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const int *idx, const double *x, const double *b, const double *dinv,
                         double omega, const double *xin, const int *agg, double *out, dim3 grid, BlockMap bm,
                         const double *hv = nullptr, int split = 0x7fffffff) {
@@ -1249,7 +1281,16 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
                                            c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
                                            ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
                                            O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB)
-#define CH_(O, UU) do { if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
+  // group sweep (views with A->sweep set; plain index codes, no halo): one workgroup per row-block group of the grouped pre pass
+  BlockMap gbm; dim3 ggrid(1);
+  const bool sweep = A->sweep && !hv && !c->vtab && op == FUSE_POST_MAPPED;
+  if (sweep) ggrid = plan_group_map(A, A->sweep, gbm);
+#define CG_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_group_kernel<O, UU, false, false>), ggrid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
+                                      c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
+                                      ctx->opt_nt_store ? -capi : capi, gbm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
+                                      nullptr, nullptr, (A->rows + RB - 1) / RB, A->sweep->gdesc)
+#define CH_(O, UU) do { if (sweep && O == FUSE_POST_MAPPED) CG_(FUSE_POST_MAPPED, UU); \
+                        else if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
                         else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
 #define CU_(O) do { if (u == 4) CH_(O, 4); else if (u == 7) CH_(O, 7); else CH_(O, 8); } while (0)
   switch (op) {
@@ -1260,11 +1301,31 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   }
 #undef CU_
 #undef CH_
+#undef CG_
 #undef C_
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
 
+
+// workgroup → group map: XCD-contiguous, strip-major for far bands (distances in groups instead of row blocks)
+static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) {
+  mgs_ctx *ctx = A->ctx;
+  bm.base = 0; bm.nblocks = G->ngroups;
+  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
+  bm.chunk = (bm.nblocks + 7) / 8;
+  bm.D = 0; bm.S = 0; bm.P = 0;
+  int per_xcd = bm.chunk;
+  if (bm.remap && ctx->opt_strip != 0) {
+    const int Db = (A->far_band + RB - 1) / RB;
+    const int D = G->plane_groups;          // groups from one far-band period to the next (setup: first blocks Db apart)
+    if (Db >= 512 && D >= 64 && bm.chunk >= 2 * D) {
+      bm.D = D; bm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 32; bm.P = (bm.chunk + D - 1) / D;
+      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+    }
+  }
+  return dim3(bm.remap ? per_xcd * 8 : bm.nblocks);
+}
 
 void mgs_free_groups(mgs_groups *g) {
   if (!g) return;
@@ -1392,22 +1453,8 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
   const bool lean = c && (double)c->coded_blocks >= 0.985 * c->nblocks;
   const int capi = lean ? std::max(c->tab_cap, 64) : std::max(c ? c->tab_cap : 0, capv + 2);
   const size_t lds = (size_t)(capv + 2) * 8 + (size_t)((capi + 1) / 2) * 8 + (size_t)G->max_blocks * RB * 8 + 16 + (size_t)ctx->opt_lds_pad;
-  // workgroup → group map: XCD-contiguous, strip-major for far bands (distances in groups instead of row blocks)
   BlockMap bm;
-  bm.base = 0; bm.nblocks = G->ngroups;
-  bm.remap = ctx->opt_xcd_remap && bm.nblocks >= 64;
-  bm.chunk = (bm.nblocks + 7) / 8;
-  bm.D = 0; bm.S = 0; bm.P = 0;
-  int per_xcd = bm.chunk;
-  if (bm.remap && ctx->opt_strip != 0) {
-    const int Db = (A->far_band + RB - 1) / RB;
-    const int D = G->plane_groups;          // groups from one far-band period to the next (setup: first blocks Db apart)
-    if (Db >= 512 && D >= 64 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 32; bm.P = (bm.chunk + D - 1) / D;
-      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
-    }
-  }
-  const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  const dim3 grid = plan_group_map(A, G, bm);
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
   const bool pairs = G->max_blocks <= 2 && ctx->opt_group_concurrent;     // 512 threads, both blocks of a pair at once

@@ -139,6 +139,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "group_min_link") ctx->opt_group_min_link = value;
   else if (k == "group_concurrent") ctx->opt_group_concurrent = value;
+  else if (k == "group_sweep") ctx->opt_group_sweep = value;
   else if (k == "group_min_blocks") ctx->opt_group_min_blocks = value;
   else if (k == "native_graph") ctx->opt_native_graph = value;
   else if (k == "native_overlap") ctx->opt_native_overlap = value;
@@ -884,6 +885,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       MGS_TRY(mgs_launch_group_pre(&Ahat, L.grp, L.T, b, b, L.r->d, L.tmp->d, C.b->d, hv, L.A->rows));
       MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
       MGS_TRY(payload(1, C.x->d, L.T->agg));
+      if (ctx->opt_group_sweep & 1) Amap.sweep = L.grp;
       if (halo) return mgs_launch_coded_range(&Amap, FUSE_POST_MAPPED, C.x->d, L.r->d, L.wd->d, 0.0, nullptr, L.T->agg, x, hv, L.T->n_coarse, 0, nb);
       return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, L.r->d, nullptr, L.T->agg, C.x->d, x, nullptr, nullptr, 0, nb);
     }

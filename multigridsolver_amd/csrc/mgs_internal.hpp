@@ -42,6 +42,7 @@ struct mgs_ctx {
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
   int opt_group_min_blocks = 1024;  // ... levels with fewer row blocks keep the separate kernels
+  int opt_group_sweep = 0;       // bit 0: the t-form post pass sweeps the grouped pre pass's row-block groups (one workgroup per group) instead of single blocks
   int opt_group_concurrent = 0;  // groups of ≤ 2 blocks: 512-thread workgroups sweep both blocks at once (csr_group2_pre_kernel; same bits; measured at 512³:
                                  // 6.59 ms per cycle against 6.50 for the sequential sweep of the same pairs and 6.13 for 4-block groups — kept for A/B)
   int opt_group_min_link = 1;   // ... aggregates two row blocks must share to be grouped (8: keeps a few odd boundary aggregates from pulling blocks of
@@ -92,6 +93,7 @@ struct mgs_csr {
   bool code_tried = false;
   // views made by mgs_spmv_dots only: (y·w1, y·y) of the product y = A·x accumulated in the SpMV's epilogue (one partial pair per row block)
   const double *dot_w1 = nullptr; double *dot_part = nullptr;
+  const struct mgs_groups *sweep = nullptr;   // views only: launch the coded kernel group by group over these row-block groups (option group_sweep)
   const unsigned char *dpos = nullptr;   // views of the t-form post pass only (not owned): position of the diagonal inside every row, so the
   double dpos_omega = 0.0;               // kernel takes ω/a_ii from the values it streams anyway instead of reading wd (8 B → 1 B per row)
   int *origin = nullptr;   // coarse operators built by the device setup: the finest-level row each row descends from (its aggregate's

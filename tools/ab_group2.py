@@ -10,7 +10,7 @@ N = int(sys.argv[1]); sets = sys.argv[2:]
 ctx = mg.Context(0)
 A = ctx.poisson3d(N); n = N ** 3
 b = ctx.vec(n).rand(seed=0)
-DEFAULTS = "fuse_restrict=1,group_min_link=1,group_blocks=4,group_stray_pct=6,diag_from_values=1,group_concurrent=0"
+DEFAULTS = "fuse_restrict=1,group_min_link=1,group_blocks=4,group_stray_pct=6,diag_from_values=1,group_concurrent=0,group_sweep=0"
 
 
 def apply(sset):
