@@ -57,6 +57,22 @@ for t in range(trials):
         ctx.set_option("fuse_operands", 0); cg = h.vcycle(b).numpy(); ctx.set_option("fuse_operands", 1)
         assert np.array_equal(c0, c1), (t, "cycle bits", dim, N)
         assert np.linalg.norm(cg - c1) <= 1e-12 * np.linalg.norm(c1), (t, "operand form", dim, N)
+        # grouped pre pass forced onto these small, defective operators (any stray share, any level size): a second hierarchy (groups
+        # are built once) against the separate kernels; coded vs plain index and ω/a_ii vs wd must not change a bit
+        ctx.set_option("group_min_blocks", 1); ctx.set_option("group_stray_pct", 100); ctx.set_option("group_blocks", int(rng.choice([2, 3, 4])))
+        ctx.set_option("group_concurrent", int(t % 2))
+        hg = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, coarse_rows=max(50, n // 60), max_levels=8).finalize()
+        g1 = hg.vcycle(b).numpy()
+        stats["grouped_levels"] = stats.get("grouped_levels", 0) + sum(1 for l in range(hg.nlev - 1) if hg.group_info(l)["groups"] > 0)
+        stats["stray_aggs"] = stats.get("stray_aggs", 0) + sum(hg.group_info(l)["stray_aggregates"] for l in range(hg.nlev - 1))
+        ctx.set_option("rowcode", 0); g0 = hg.vcycle(b).numpy(); ctx.set_option("rowcode", 1)
+        ctx.set_option("diag_from_values", 0); gw = hg.vcycle(b).numpy(); ctx.set_option("diag_from_values", 1)
+        ctx.set_option("fuse_restrict", 0); gs = hg.vcycle(b).numpy(); ctx.set_option("fuse_restrict", 1)
+        for k, v in (("group_min_blocks", 1024), ("group_stray_pct", 6), ("group_blocks", 4), ("group_concurrent", 0)): ctx.set_option(k, v)
+        assert np.array_equal(g0, g1) and np.array_equal(gw, g1), (t, "grouped cycle bits", dim, N)
+        assert np.array_equal(gs, c1), (t, "same hierarchy, separate kernels", dim, N)
+        assert np.linalg.norm(g1 - c1) <= 1e-12 * np.linalg.norm(c1), (t, "grouped vs separate", dim, N, np.linalg.norm(g1 - c1) / np.linalg.norm(c1))
+        del hg
     # opt-in value patterns: a second copy of the operator built with valcode = 1 must reproduce the same bits
     ctx.set_option("valcode", 1)
     try:
