@@ -901,8 +901,10 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
       const double r = bi - s;
       t_out[row] = bi + r;
       rbuf[h * RB + tid] = r;
-      if ((wm >> (row & 31)) & 1u) r_out[row] = r;                        // member of a stray aggregate
     }
+    // members of stray aggregates also store r — the whole wave does when one of its rows must: 64 consecutive doubles are four full
+    // cache lines, while lone 8-byte stores each cost a read-modify-write of an ECC word in HBM
+    if (__any((int)((wm >> (row & 31)) & 1u)) && row < r1) r_out[row] = bi - s;
   }
   __syncthreads();
 #pragma unroll
@@ -1015,8 +1017,8 @@ __global__ __launch_bounds__(2 * RB) void csr_group2_pre_kernel(
     const double r = bi - s;
     t_out[row] = bi + r;
     rbuf[half * RB + tid] = r;
-    if ((wm >> (row & 31)) & 1u) r_out[row] = r;                          // member of a stray aggregate
   }
+  if (__any((int)((wm >> (row & 31)) & 1u)) && blk >= 0 && row < r1) r_out[row] = bi - s;   // whole waves: see csr_group_pre_kernel
   __syncthreads();
   for (int a = a0; a < ae; a += RB) {                                      // this half's block's aggregates; positions span both halves
     const unsigned long long code = a == a0 ? code0 : acode[a];

@@ -7,6 +7,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multigridsolver_amd as mg
 N = int(sys.argv[1]); sets = sys.argv[2:]
+REP = int(os.environ.get("AB_INSTANCES", "1"))      # hierarchies per variant (cycle time depends on where a hierarchy landed in HBM by up to ±3 %:
+sets = sets * REP                                   # with AB_INSTANCES=2 the variants alternate A B A B and every instance is listed)
 ctx = mg.Context(0)
 A = ctx.poisson3d(N); n = N ** 3
 b = ctx.vec(n).rand(seed=0)
@@ -25,11 +27,11 @@ for sset in sets:
     x = ctx.vec(n)
     for _ in range(3): h.vcycle(b, x)
     hs.append((sset, h, x, [h.group_info(l) for l in range(2)]))
-res = {s: [] for s, *_ in hs}
+res = {i: [] for i in range(len(hs))}
 for rnd in range(5):
-    for sset, h, x, _ in hs:
+    for i, (sset, h, x, _) in enumerate(hs):
         apply(sset)
         h.vcycle(b, x)
-        res[sset].append(h.time_vcycle(b, x, reps=20))
-for sset, h, x, info in hs:
-    print(f"{sset:40s} min {min(res[sset]):.3f} med {sorted(res[sset])[2]:.3f} ms   L0 {info[0]}")
+        res[i].append(h.time_vcycle(b, x, reps=20))
+for i, (sset, h, x, info) in enumerate(hs):
+    print(f"{sset:40s} min {min(res[i]):.3f} med {sorted(res[i])[2]:.3f} ms   L0 {info[0]}")
