@@ -71,11 +71,10 @@ def main(argv=None):
         sh = mgd.ShardedHierarchy(ctx, A, plan, args.omega, args.nu1, args.nu2, comm).build(args.ktg, args.npass, args.tou, tail_rows=max(20000, rows // 50))
         lo, hi = mgd.row_ranges(rows, world)[rank]
         x, b = ctx.vec(ncols), ctx.vec(bg[lo:hi])
-        ctx.sync(); dist.barrier(); t0 = time.perf_counter()
+        ctx.sync(); comm.barrier(); t0 = time.perf_counter()      # collectives on the side stream (dist.py Comm: the cycle's stream gets captured)
         st, it, tol = sh.bicgstab(x, b, args.max_iter, args.tol)
-        ctx.sync(); dist.barrier(); dt = time.perf_counter() - t0
-        parts = [None] * world
-        dist.all_gather_object(parts, x.numpy(plan.n_loc))
+        ctx.sync(); comm.barrier(); dt = time.perf_counter() - t0
+        parts = comm.all_gather_object(x.numpy(plan.n_loc))
         xs = np.concatenate(parts)
     if rank == 0:
         sys.stderr.write("    \033[1;34m[time] \033[0m%-42s : %f.\n" % ("BiCGStab_SolveTimer", dt))
