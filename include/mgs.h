@@ -183,6 +183,10 @@ int mgs_hier_set_kcycle(mgs_hier *h, int levels);
  * P·cycle(Pᵀ v) + M2(v) with M2 = ωD⁻¹ instead of the multiplicative form.  The other switch, `use_preconditioner = false`
  * (:53-54, solve(v) = v), is mgs_bicgstab / mgs_fgcr with hier = NULL.  Not offered on row shards. */
 int mgs_hier_set_additive(mgs_hier *h, int on);
+/* over-correction of unsmoothed aggregation (new knob, default 1 = the reference's form `P * (…)`, bicg.cpp:48): the coarse-grid correction of
+ * every level is scaled, x ← x + σ·P e_c.  Piecewise-constant prolongation under-corrects smooth error; σ ≈ 1.5–2 cuts the Krylov iterations of
+ * the V-cycle preconditioner on Poisson-like problems at the cost of one axpy on each coarse vector.  Parity fixtures use σ = 1. */
+int mgs_hier_set_correction_scale(mgs_hier *h, double sigma);
 int mgs_hier_destroy(mgs_hier *h);
 int mgs_hier_nlev(const mgs_hier *h);
 int mgs_hier_level_shape(const mgs_hier *h, int level, int *rows, int64_t *nnz);

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "mgs_hier_set_smoother": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     "mgs_hier_set_kcycle": (C.c_int, [C.c_void_p, C.c_int]),
     "mgs_hier_set_additive": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgs_hier_set_correction_scale": (C.c_int, [C.c_void_p, C.c_double]),
     "mgs_hier_destroy": (C.c_int, [C.c_void_p]),
     "mgs_hier_nlev": (C.c_int, [C.c_void_p]),
     "mgs_hier_level_shape": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_i64_p]),

@@ -309,6 +309,10 @@ class Hierarchy:
     def set_kcycle(self, levels):
         check(lib().mgs_hier_set_kcycle(self.h, levels), self.ctx.h); return self
 
+    def set_correction_scale(self, sigma):
+        """over-correction x ← x + σ·P e_c on every level (σ = 1: the reference's form)"""
+        check(lib().mgs_hier_set_correction_scale(self.h, float(sigma)), self.ctx.h); return self
+
     def set_additive(self, on=True):
         """additive form of solve() (reference bicg.cpp:59)"""
         check(lib().mgs_hier_set_additive(self.h, int(bool(on))), self.ctx.h); return self

@@ -517,6 +517,11 @@ int mgs_hier_set_kcycle(mgs_hier *h, int levels) {
   h->kcycle_levels = levels; drop_graph(h);
   return MGS_OK;
 }
+int mgs_hier_set_correction_scale(mgs_hier *h, double sigma) {
+  MGS_CHECK(h->ctx, sigma > 0.0 && sigma <= 4.0, MGS_ERR_INVALID, "mgs_hier_set_correction_scale: sigma must lie in (0, 4]");
+  h->corr_scale = sigma; drop_graph(h);
+  return MGS_OK;
+}
 int mgs_hier_set_additive(mgs_hier *h, int on) {
   MGS_CHECK(h->ctx, !on || (!h->halo && !h->halo_begin && !h->native), MGS_ERR_STATE, "mgs_hier_set_additive: not offered on row shards");
   h->additive = on != 0; drop_graph(h);
@@ -743,7 +748,15 @@ static int kc_allreduce(mgs_hier *h, double *dev, int cnt) {
   return MGS_OK;
 }
 static int sharded_op(mgs_hier *h, int l, const mgs_csr *A, int op, double *x, const double *b, const double *dinv, double omega, double *out);
+static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x);
+// e_c for the level above; with an over-correction factor σ ≠ 1 (mgs_hier_set_correction_scale) it is scaled here, once, on the
+// coarse vector (n_c entries), so every form of the level above — fused, grouped, unfused, K-cycle — sees σ·e_c
 static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
+  MGS_TRY(coarse_solve_inner(h, l, rhs, x));
+  if (h->corr_scale != 1.0) MGS_TRY(k_axpby(h->ctx, h->lev[l].n, h->corr_scale, x, 0.0, x));
+  return MGS_OK;
+}
+static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x) {
   if (!kcycle_here(h, l)) return cycle_level(h, l, rhs, x, true);
   mgs_ctx *ctx = h->ctx;
   mgs_level &L = h->lev[l];

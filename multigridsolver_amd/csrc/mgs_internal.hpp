@@ -191,6 +191,7 @@ struct mgs_hier {
   int nu1 = 1, nu2 = 1;
   bool finalized = false;
   int kcycle_levels = 0;   // levels 1..kcycle_levels solve their coarse problem with 2 GCR steps (K-cycle)
+  double corr_scale = 1.0; // over-correction: x ← x + σ·P e_c (σ = 1: the reference's form, bicg.cpp:48)
   bool additive = false;   // bicg.cpp:59: multigrid_solve(v) + M2(v) instead of the multiplicative form (M2 = ωD⁻¹)
   // coarsest direct solve
   int nc = 0;

@@ -308,6 +308,7 @@ struct orc_hier {
   orc_dense_lu lu;
   double omega; int nu1, nu2;
   int kcycle_levels;
+  double corr_scale;   /* over-correction x += sigma * P e_c (0 or 1: the reference's form) */
   int additive;   /* bicg.cpp:59: multigrid_solve(v) + M2(v) instead of the multiplicative form */
   double **kc1, **kv1, **kc2, **kv2, **kr;
 };
@@ -371,6 +372,7 @@ int orc_hier_nlev(const orc_hier *h) { return h->nlev; }
 void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2) { h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; }
 void orc_hier_set_kcycle(orc_hier *h, int levels) { h->kcycle_levels = levels; }
 void orc_hier_set_additive(orc_hier *h, int on) { h->additive = on; }
+void orc_hier_set_correction_scale(orc_hier *h, double sigma) { h->corr_scale = sigma; }
 const orc_csr *orc_hier_A(const orc_hier *h, int l) { return &h->A[l]; }
 
 /* V-cycle definition (SURVEY §7 "Hard parts"; two-level ν1=0, ν2=1 from x=0
@@ -383,7 +385,12 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
 /* Coarse solve for the level above: one cycle (V), or two GCR steps preconditioned by the cycle
  * (K-cycle; docs/AGMG_For_Convection_Diffusion.pdf §3.1 — derived from the paper, the reference's
  * C++ has no K-cycle):  x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1. */
+static void coarse_solve_inner(const orc_hier *h, int l, const double *rhs, double *x);
 static void coarse_solve_rec(const orc_hier *h, int l, const double *rhs, double *x) {
+  coarse_solve_inner(h, l, rhs, x);
+  if (h->corr_scale != 0.0 && h->corr_scale != 1.0) for (int i = 0; i < h->A[l].rows; i++) x[i] = h->corr_scale * x[i];
+}
+static void coarse_solve_inner(const orc_hier *h, int l, const double *rhs, double *x) {
   if (!(l >= 1 && l <= h->kcycle_levels && l < h->nlev - 1)) { vcycle_rec(h, l, rhs, x, 1); return; }
   const orc_csr *A = &h->A[l];
   int n = A->rows;

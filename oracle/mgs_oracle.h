@@ -86,6 +86,7 @@ void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2);
  * paper (docs/AGMG_For_Convection_Diffusion.pdf §3.1): no executable reference exists for it. */
 void orc_hier_set_kcycle(orc_hier *h, int levels);
 void orc_hier_set_additive(orc_hier *h, int on);   /* bicg.cpp:59 */
+void orc_hier_set_correction_scale(orc_hier *h, double sigma);   /* x += sigma * P e_c; derived knob, no reference counterpart */
 const orc_csr *orc_hier_A(const orc_hier *h, int l);
 /* x = Vcycle(b) from x = 0 (zero_guess != 0) or from the x passed in */
 void orc_vcycle(const orc_hier *h, const double *b, double *x, int zero_guess);

@@ -56,6 +56,7 @@ def lib():
         L.orc_hier_set_smoother.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]; L.orc_hier_set_smoother.restype = None
         L.orc_hier_set_kcycle.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_kcycle.restype = None
         L.orc_hier_set_additive.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_additive.restype = None
+        L.orc_hier_set_correction_scale.argtypes = [C.c_void_p, C.c_double]; L.orc_hier_set_correction_scale.restype = None
         L.orc_hier_A.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_A.restype = cp
         L.orc_vcycle.argtypes = [C.c_void_p, dp, dp, C.c_int]; L.orc_vcycle.restype = None
         L.orc_bicgstab.argtypes = [cp, dp, dp, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -241,6 +242,11 @@ class Hier:
 
     def set_kcycle(self, levels):
         lib().orc_hier_set_kcycle(self.h, levels)
+        return self
+
+    def set_correction_scale(self, sigma):
+        """x ← x + σ·P e_c on every level (derived knob; σ = 1 is the reference's form)"""
+        lib().orc_hier_set_correction_scale(self.h, float(sigma))
         return self
 
     def set_additive(self, on=True):

@@ -20,4 +20,12 @@ for npass in (2, 3):
         st, it, tol = mg.bicgstab(A, x, b, h, 400, 1e-10)
         dt = time.perf_counter() - t0
         print(f"  V({n1},{n2}) omega={w}: cycle {ms:.2f} ms, status {st}, {it} iterations, {dt:.2f} s", flush=True)
+    for sigma in (1.3, 1.6, 1.8, 2.0, 2.3):                 # over-correction x += sigma * P e_c, with the default smoother and with omega = 0.8
+        for w in (0.6, 0.8):
+            h.set_smoother(w, 1, 1); h.set_correction_scale(sigma)
+            x = ctx.vec(n); h.vcycle(b, x); x.fill(0.0); ctx.sync()
+            t0 = time.perf_counter()
+            st, it, tol = mg.bicgstab(A, x, b, h, 400, 1e-10)
+            print(f"  sigma={sigma} omega={w}: status {st}, {it} iterations, {time.perf_counter() - t0:.2f} s", flush=True)
+    h.set_correction_scale(1.0)
     del h
