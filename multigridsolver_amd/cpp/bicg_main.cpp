@@ -4,7 +4,7 @@
 // tag "device" = no P file: the whole hierarchy is aggregated on the GPU), builds the
 // preconditioner, fills b with srand(0)/rand() (bicg.cpp:139,159-162), runs BiCGSTABiml with
 // tol 1e-6 and max_iter 10000 (bicg.cpp:148,164) and prints the reference's two [info] lines.
-// Environment knobs (new; the reference has no smoother options): MGS_OMEGA, MGS_NU1, MGS_NU2,
+// Environment knobs (new; the reference has no smoother options): MGS_OMEGA, MGS_NU1, MGS_NU2, MGS_SIGMA (over-correction),
 // MGS_ADDITIVE=1 / MGS_NO_PRECOND=1 (the reference's two dead solve() switches, bicg.cpp:42-43,53-59),
 // MGS_TOL, MGS_MATRIX_DIR, MGS_GENERIC=1 (run the generic operator-overloading BiCGSTABiml
 // template instead of the fused device path).
@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
     if ((e = getenv("MGS_OMEGA"))) opt.omega = atof(e);
     if ((e = getenv("MGS_NU1"))) opt.nu1 = atoi(e);
     if ((e = getenv("MGS_NU2"))) opt.nu2 = atoi(e);
+    if ((e = getenv("MGS_SIGMA"))) opt.correction_scale = atof(e);
     if ((e = getenv("MGS_ADDITIVE"))) opt.multiplicative_precond = atoi(e) == 0;      // the reference's two dead switches (bicg.cpp:42-43)
     if ((e = getenv("MGS_NO_PRECOND"))) opt.use_preconditioner = atoi(e) == 0;
 

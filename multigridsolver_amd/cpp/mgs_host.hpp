@@ -143,6 +143,7 @@ class DeviceMatrix {
 // bicg.cpp:46-61 with M2 = ωD⁻¹.
 struct PrecondOptions {
   double omega = 0.6; int nu1 = 1, nu2 = 1;
+  double correction_scale = 1.0;                         // x ← x + σ·P e_c; 1 = the reference's form (bicg.cpp:48)
   double ktg = 10.0; int npass = 2; double tou = 8.0;   // src/GPU_CUDAC++/results.txt:22-24
   int coarse_rows = 2500; int max_levels = 32;   // ≤ 2500 rows: dense inverse (a GEMV beats two more latency-bound levels)
   // the two switches of the reference's solve() (bicg.cpp:42-43,53-59; both fixed to true there):
@@ -176,6 +177,7 @@ class MultiGridPrecond {
     check(mgs_hier_coarsen(h, o.ktg, o.npass, o.tou, o.coarse_rows, o.max_levels), context());
     check(mgs_hier_finalize(h), context());
     if (!o.multiplicative_precond) check(mgs_hier_set_additive(h, 1), context());
+    if (o.correction_scale != 1.0) check(mgs_hier_set_correction_scale(h, o.correction_scale), context());
     use_preconditioner_ = o.use_preconditioner;
   }
 };
