@@ -694,6 +694,8 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                "cpu_baseline": None}
     beat("teardown")
     comm.barrier()
+    if rank != 0:
+        launch.mark_done()           # this rank's part is complete: a crash while tearing RCCL down must not restart the generation
     try:
         sh.close()
         del sh, b, x, xs, y, A

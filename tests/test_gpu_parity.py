@@ -574,6 +574,17 @@ def test_properties_full_size_512(ctx, mg):
         ctx.set_option("fuse", 1)
     mg.lib().mgs_axpby(-1.0, Bu.h, 1.0, Bu0.h)
     assert Bu0.nrm2() <= 1e-12 * Bu.nrm2()
+    # grouped pre pass (restriction inside the pre pass) at full size: the fine level qualifies (aligned matching: a handful of strays),
+    # and the cycle agrees with the separate kernels to rounding
+    gi = h.group_info(0)
+    assert gi["groups"] > 0 and gi["stray_aggregates"] <= 0.01 * r1, gi
+    ctx.set_option("fuse_restrict", 0)
+    try:
+        Bu0 = h.vcycle(u)
+    finally:
+        ctx.set_option("fuse_restrict", 1)
+    mg.lib().mgs_axpby(-1.0, Bu.h, 1.0, Bu0.h)
+    assert Bu0.nrm2() <= 1e-13 * Bu.nrm2()
     # pattern-coded index vs the plain CSR kernels at full size: the same bits, kernel and cycle
     assert A.rowcode_info()["coded_blocks"] == A.rowcode_info()["blocks"] == n // 256
     ctx.set_option("rowcode", 0)
@@ -590,6 +601,9 @@ def test_properties_full_size_512(ctx, mg):
     assert st == 1 and it == 30 and tol < 0.2, (st, it, tol)          # status 1 = max_iter (bicg.cpp:134-135)
     true = A.residual(x, u).nrm2() / u.nrm2()
     assert abs(true - tol) <= 1e-6 * tol, (true, tol)
+    # ... and the solve reaches 1e-10 (north_star bar) in the iteration count of the aligned hierarchy
+    x = ctx.vec(n); st, it, tol = mg.bicgstab(A, x, u, h, 200, 1e-10)
+    assert st == 0 and it <= 80 and A.residual(x, u).nrm2() / u.nrm2() <= 1.5e-10, (st, it, tol)
 
 
 def test_kcycle_vs_oracle(ctx, mg, orc):
