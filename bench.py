@@ -367,6 +367,7 @@ def main():
     t_solve_t = time.perf_counter() - t0
     truet = A.residual(xt, b).nrm2() / r0
     h.set_smoother(args.omega, args.nu1, args.nu2).set_correction_scale(1.0)
+    h.vcycle(b, x)                                            # back on the default knobs (operands rescaled, cycle re-captured)
     log(f"tuned knobs (omega 0.8, over-correction 1.6): status {stt}, {itt} iterations, true residual {truet:.2e}, {t_solve_t:.2f}s")
     del xt
     # K-cycle on the first 4 coarse levels + flexible GCR(10), untimed region as well
