@@ -1546,7 +1546,7 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
                            const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi, int gap_at, int gap_len) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
-  if (A->lds_cap <= 0 || (A->rows != A->cols && !hv)) return MGS_ERR_STATE;
+  if (A->lds_cap <= 0 || (which != FUSE_POST_MAPPED && A->rows != A->cols && !hv)) return MGS_ERR_STATE;   // (the mapped operand may be A·P: n × n_c)
   BlockMap bm;
   bm.gap_at = gap_at; bm.gap_len = gap_len;
   bm.base = blk_lo; bm.nblocks = blk_hi - blk_lo;

@@ -135,6 +135,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "fuse_restrict") ctx->opt_fuse_restrict = value;
   else if (k == "diag_from_values") ctx->opt_diag_from_values = value;
   else if (k == "fuse_dots") ctx->opt_fuse_dots = value;
+  else if (k == "merge_ap") ctx->opt_merge_ap = value;
   else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "group_min_link") ctx->opt_group_min_link = value;
@@ -401,6 +402,8 @@ static void level_free(mgs_level &L) {
   if (L.val_wd) hipFree(L.val_wd);
   if (L.col_agg) hipFree(L.col_agg);
   mgs_free_rowcode(L.code_agg);
+  if (L.AP) mgs_csr_destroy(L.AP);
+  mgs_free_rowcode(L.code_ap);
   mgs_free_rowcode(L.code_pre);
   mgs_free_rowcode(L.code_hat);
   mgs_free_groups(L.grp);
@@ -634,8 +637,8 @@ int mgs_hier_fused_info(const mgs_hier *h, int level, int64_t out[6]) {
   MGS_CHECK(h->ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_fused_info: level %d out of range", level);
   const mgs_level &L = h->lev[level];
   auto coded = [](const mgs_rowcode *c) -> int64_t { return c ? c->coded_blocks : 0; };
-  out[0] = (L.A->rows + 255) / 256; out[1] = L.val_wd != nullptr; out[2] = L.col_agg != nullptr;
-  out[3] = coded(L.A->code); out[4] = coded(L.code_pre); out[5] = coded(L.code_agg);
+  out[0] = (L.A->rows + 255) / 256; out[1] = L.val_wd != nullptr; out[2] = L.col_agg != nullptr || L.AP != nullptr;
+  out[3] = coded(L.A->code); out[4] = coded(L.code_pre); out[5] = coded(L.AP ? L.code_ap : L.code_agg);
   return MGS_OK;
 }
 
@@ -860,7 +863,8 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     Ahat.code = halo ? L.code_pre : ((L.A->code && L.A->code->vtab) || L.code_hat ? L.code_hat : L.A->code);
     mgs_csr Amap = *L.A; Amap.val = L.A->val; Amap.col = L.col_agg; Amap.code = L.code_agg; Amap.owns = false;
     if (ctx->opt_diag_from_values && L.dpos) { Amap.dpos = L.dpos; Amap.dpos_omega = h->omega; }   // t-form post pass: ω/a_ii from the streamed values
-    const bool operands = ctx->opt_fuse_operands && L.val_wd && L.col_agg &&
+    if (ctx->opt_merge_ap && L.AP) { Amap = *L.AP; Amap.code = L.code_ap; Amap.owns = false; }      // A·P, merged: fewer entries, wd read per row
+    const bool operands = ctx->opt_fuse_operands && L.val_wd && (L.col_agg || (ctx->opt_merge_ap && L.AP)) &&
                           (!halo || (mgs_rowcode_usable(&Ahat, true) && mgs_rowcode_usable(&Amap, true)));
     auto coded_pass = [&](const mgs_csr *V, int op, int kind, const void *pa, const void *pb, const double *xsrc, const double *bvec,
                           const double *dv, const double *xin, const int *agg, double *out, int isplit) -> int {
@@ -975,13 +979,20 @@ static int prepare_fused(mgs_hier *h) {
       bool new_vals = false;
       if (!L.val_wd) { MGS_TRY(mgs_dev_alloc(ctx, &L.val_wd, (size_t)L.A->nnz + 4)); MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); drop_graph(h); new_vals = true; }
       else if (rescale) { MGS_TRY(k_scale_vals(ctx, L.A, L.wd->d, L.val_wd)); new_vals = true; }
-      if (!L.col_agg) {
+      if (ctx->opt_merge_ap && !L.AP) {
+        MGS_TRY(k_build_ap(L.A, L.T, &L.AP)); drop_graph(h);
+        L.AP->far_band = L.A->far_band; L.AP->far_band_max = L.A->far_band_max;     // sweep order of the launch: the band of A (AP's columns are coarse ids)
+        if (ctx->opt_rowcode)
+          MGS_TRY(mgs_build_rowcode(ctx, L.AP->rows, L.AP->rowptr, L.AP->col, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_ap,
+                                    ctx->opt_valcode ? L.AP->val : nullptr));
+      }
+      if (!ctx->opt_merge_ap && !L.col_agg) {
         MGS_TRY(mgs_dev_alloc(ctx, &L.col_agg, (size_t)L.A->nnz + 4)); MGS_TRY(k_map_cols(ctx, L.A, L.T->agg, L.T->n_coarse, L.col_agg)); drop_graph(h);
         if (ctx->opt_rowcode)
           MGS_TRY(mgs_build_rowcode(ctx, L.A->rows, L.A->rowptr, L.col_agg, L.T->agg, shard ? L.T->n_coarse : 0x7fffffff, &L.code_agg,
                                     ctx->opt_valcode ? L.A->val : nullptr));
       }
-      if (ctx->opt_diag_from_values && !L.dpos) {
+      if (ctx->opt_diag_from_values && !L.dpos && !ctx->opt_merge_ap) {
         MGS_TRY(mgs_dev_alloc(ctx, &L.dpos, (size_t)L.A->rows)); MGS_TRY(k_diag_pos(L.A, L.dpos)); drop_graph(h);
       }
       if (ctx->opt_fuse_restrict && !L.grp_tried) {   // row-block groups of the grouped pre pass (null: level does not qualify)

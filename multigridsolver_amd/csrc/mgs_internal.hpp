@@ -38,6 +38,7 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_merge_ap = 1;          // fused post pass on A·P (merged entries) instead of A with aggregate-mapped columns
   int opt_fuse_dots = 1;         // BiCGSTAB: r̃·v and (t·s, t·t) in the epilogue of the SpMV that produces v resp. t
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
   int opt_fuse_restrict = 1;  // grouped pre pass: restriction inside the pre-smoothing/residual pass, post pass reads t = b + r
@@ -172,6 +173,8 @@ struct mgs_level {
   double *val_wd = nullptr;    // setup-time operand of the fused pre pass: a_ij·wd_j, so A·(wd∘b) = Â·b needs one gather
   int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
+  mgs_csr *AP = nullptr;             // setup-time operand of the fused post pass, option merge_ap: A·P with the entries of a row that fall into one
+  mgs_rowcode *code_ap = nullptr;    // aggregate summed (5 instead of 7 entries per row on the 7-point operator) and its pattern code (offsets from agg[row])
   mgs_rowcode *code_pre = nullptr;   // row shards: pattern code of col with tagged halo words (pre pass reads b + payload)
   mgs_rowcode *code_hat = nullptr;   // option valcode: pattern code of (col, val_wd) for the pre pass on Â
   unsigned char *dpos = nullptr;     // position of the diagonal entry inside each row (255: none / beyond 254), see mgs_csr::dpos
@@ -306,6 +309,7 @@ int k_transpose(const mgs_csr *A, mgs_csr **out);
 // (setup_agmg.hip)
 int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host);
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
+int k_build_ap(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
 int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out);
 int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_host, mgs_xfer **out);
 int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);

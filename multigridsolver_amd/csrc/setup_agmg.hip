@@ -131,7 +131,8 @@ __global__ void galerkin_ub_kernel(int nc, const int *__restrict__ cptr, const i
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > nc) return;
   int s = 0;
-  if (c < nc) for (int k = cptr[c]; k < cptr[c + 1]; ++k) { int i = members[k]; s += rowptr[i + 1] - rowptr[i]; }
+  if (c < nc && !cptr) s = rowptr[c + 1] - rowptr[c];           // identity member lists: row c alone
+  else if (c < nc) for (int k = cptr[c]; k < cptr[c + 1]; ++k) { int i = members[k]; s += rowptr[i + 1] - rowptr[i]; }
   ub[c] = s;
 }
 // one lane per coarse row: gather (agg(col), val) of all member rows, insertion-sort by
@@ -144,8 +145,9 @@ __global__ void galerkin_fill_kernel(int nc, const int *__restrict__ cptr, const
   if (c == nc) { uniq[c] = 0; return; }
   const int base = offs[c];
   int cnt = 0;
-  for (int m = cptr[c]; m < cptr[c + 1]; ++m) {
-    int i = members[m];
+  const int m0 = cptr ? cptr[c] : c, m1 = cptr ? cptr[c + 1] : c + 1;
+  for (int m = m0; m < m1; ++m) {
+    int i = cptr ? members[m] : m;
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
       int a = agg[col[k]];
       if (a < 0) continue;
@@ -501,6 +503,19 @@ int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_
   return inherit();
 }
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) { return k_galerkin_agg_ext(A, T, nullptr, 0, out); }
+
+// A·P for an aggregation P (rows of A, one column per aggregate; on a row shard the halo columns keep one column each behind
+// them: n_coarse + slot): the entries of a row that fall into one aggregate are summed in ascending column order, entries of
+// columns outside every aggregate drop out.  Setup-time operand of the fused post pass (A·(P e_c) = (A·P) e_c).
+int k_build_ap(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+  mgs_ctx *ctx = A->ctx;
+  MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows <= A->cols, MGS_ERR_INVALID, "A·P: shape mismatch");
+  if (A->rows == A->cols) return galerkin_core(A, A->rows, nullptr, nullptr, T->agg, T->n_coarse, out);
+  DevBuf cm;
+  MGS_TRY(dalloc<int>(ctx, cm, (size_t)A->cols));
+  hipLaunchKernelGGL(colmap_ext_kernel, dim3(mgs_grid(A->cols, TB)), dim3(TB), 0, ctx->stream, A->rows, A->cols, T->n_coarse, T->agg, (const int *)nullptr, cm.as<int>());
+  return galerkin_core(A, A->rows, nullptr, nullptr, cm.as<int>(), T->n_coarse + (A->cols - A->rows), out);
+}
 
 // general P (not an aggregation): host Gustavson product, as the reference does with Eigen on
 // the CPU at setup (bicg.cpp:33).  Setup only — never on the solve path.

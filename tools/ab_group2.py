@@ -12,7 +12,7 @@ sets = sets * REP                                   # with AB_INSTANCES=2 the va
 ctx = mg.Context(0)
 A = ctx.poisson3d(N); n = N ** 3
 b = ctx.vec(n).rand(seed=0)
-DEFAULTS = "fuse_restrict=1,group_min_link=1,group_blocks=4,group_stray_pct=6,diag_from_values=1,group_concurrent=0,group_sweep=0"
+DEFAULTS = "fuse_restrict=1,group_min_link=1,group_blocks=4,group_stray_pct=6,diag_from_values=1,group_concurrent=0,group_sweep=0,merge_ap=1"
 
 
 def apply(sset):
