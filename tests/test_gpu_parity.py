@@ -170,9 +170,15 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
         ctx.set_option("group_min_blocks", 1)
         ctx.set_option("fuse_restrict", 1); xg = h.vcycle(b).numpy()
         info = [h.group_info(l) for l in range(h.nlev - 1)]
+        ctx.set_option("rowcode", 0); xp = h.vcycle(b).numpy(); ctx.set_option("rowcode", 1)
+        assert np.array_equal(xg, xp)                                          # A·P through the plain-index kernel: same bits as its pattern code
+        # option merge_ap (default on: the post pass runs on A·P with the entries of one aggregate summed) against the post pass on A with
+        # aggregate-mapped columns: the same sum in another association
+        ctx.set_option("merge_ap", 0); xm = h.vcycle(b).numpy()
         ctx.set_option("diag_from_values", 0); xw = h.vcycle(b).numpy()      # t-form post pass reading the wd vector instead of a_ii
-        ctx.set_option("diag_from_values", 1)
-        assert np.array_equal(xg, xw)                                          # ω·(1/a_ii) either way: same bits
+        ctx.set_option("diag_from_values", 1); ctx.set_option("merge_ap", 1)
+        assert np.array_equal(xm, xw)                                          # ω·(1/a_ii) either way: same bits
+        assert rel(xg, xm) <= 1e-13, rel(xg, xm)
         ctx.set_option("fuse_restrict", 0); xs = h.vcycle(b).numpy()
         # groups of at most two row blocks run the concurrent 512-thread form (csr_group2_pre_kernel): its own hierarchy (groups are built once)
         ctx.set_option("fuse_restrict", 1); ctx.set_option("group_blocks", 2); ctx.set_option("group_concurrent", 1)
@@ -183,7 +189,7 @@ def test_grouped_pre_pass_matches_separate_kernels(ctx, mg, orc, inputs, kind):
         assert np.array_equal(h2.vcycle(b).numpy(), x2)                        # sequential form over the same pairs: same bits
     finally:
         ctx.set_option("fuse_restrict", 1); ctx.set_option("group_stray_pct", 6); ctx.set_option("group_min_blocks", 1024)
-        ctx.set_option("group_blocks", 4); ctx.set_option("group_concurrent", 0)
+        ctx.set_option("group_blocks", 4); ctx.set_option("group_concurrent", 0); ctx.set_option("merge_ap", 1); ctx.set_option("rowcode", 1)
     assert info[0]["groups"] > 0, info                      # the device matching numbers aggregates by their leader: level 0 qualifies
     assert rel(xg, xs) <= 1e-13, (rel(xg, xs), info)
     # oracle cycle on the downloaded hierarchy

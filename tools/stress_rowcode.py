@@ -55,6 +55,10 @@ for t in range(trials):
         c1 = h.vcycle(b).numpy()
         ctx.set_option("rowcode", 0); c0 = h.vcycle(b).numpy(); ctx.set_option("rowcode", 1)
         ctx.set_option("fuse_operands", 0); cg = h.vcycle(b).numpy(); ctx.set_option("fuse_operands", 1)
+        ctx.set_option("merge_ap", 0); cm = h.vcycle(b).numpy()                    # post pass on A with mapped columns instead of the merged A·P
+        ctx.set_option("rowcode", 0); cm0 = h.vcycle(b).numpy(); ctx.set_option("rowcode", 1); ctx.set_option("merge_ap", 1)
+        assert np.array_equal(cm, cm0), (t, "cycle bits, unmerged operand", dim, N)
+        assert np.linalg.norm(cm - c1) <= 1e-12 * np.linalg.norm(c1), (t, "merged vs unmerged A·P", dim, N)
         assert np.array_equal(c0, c1), (t, "cycle bits", dim, N)
         assert np.linalg.norm(cg - c1) <= 1e-12 * np.linalg.norm(c1), (t, "operand form", dim, N)
         # grouped pre pass forced onto these small, defective operators (any stray share, any level size): a second hierarchy (groups
