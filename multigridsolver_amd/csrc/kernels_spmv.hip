@@ -1325,7 +1325,7 @@ static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) 
     const int Db = (A->far_band + RB - 1) / RB;
     const int D = G->plane_groups;          // groups from one far-band period to the next (setup: first blocks Db apart)
     if (Db >= 512 && D >= 64 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 32; bm.P = (bm.chunk + D - 1) / D;
+      bm.D = D; bm.S = ctx->opt_group_strip > 0 ? ctx->opt_group_strip : (ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 32); bm.P = (bm.chunk + D - 1) / D;
       per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
     }
   }

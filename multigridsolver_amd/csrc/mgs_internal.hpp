@@ -38,6 +38,7 @@ struct mgs_ctx {
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
+  int opt_group_strip = 0;       // groups per strip of the grouped pre pass's strip-major sweep (0: from opt_strip)
   int opt_merge_ap = 1;          // fused post pass on A·P (merged entries) instead of A with aggregate-mapped columns
   int opt_fuse_dots = 1;         // BiCGSTAB: r̃·v and (t·s, t·t) in the epilogue of the SpMV that produces v resp. t
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)

@@ -127,51 +127,72 @@ __global__ void p_to_agg_kernel(int n, int ncols, const int *__restrict__ rowptr
 }
 
 // ------------------------------------------------------------------ Galerkin (aggregation P)
-__global__ void galerkin_ub_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ rowptr, int *__restrict__ ub) {
+// One lane per coarse row keeps the row's (coarse column, value) pairs sorted and unique while it walks its member rows (fine order
+// i↑, j↑): an entry whose column is already there is ADDED to it, a new column is inserted — the same sums in the same order as
+// sort-by-key + reduce, without the sort.  The pairs live in LDS ([slot][lane]: conflict-free), CAP slots per lane; a row that needs
+// more continues in global memory (count pass: quadratic distinct count; fill pass: its own output segment).  Two passes (count →
+// scan → fill) instead of an nnz-sized scratch copy.  cptr == NULL: identity member lists (row c alone — A·P).
+__global__ void galerkin_maxub_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ rowptr, int *__restrict__ mx) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > nc) return;
   int s = 0;
-  if (c < nc && !cptr) s = rowptr[c + 1] - rowptr[c];           // identity member lists: row c alone
+  if (c < nc && !cptr) s = rowptr[c + 1] - rowptr[c];
   else if (c < nc) for (int k = cptr[c]; k < cptr[c + 1]; ++k) { int i = members[k]; s += rowptr[i + 1] - rowptr[i]; }
-  ub[c] = s;
+  for (int off = 32; off > 0; off >>= 1) s = max(s, __shfl_down(s, off));
+  if ((threadIdx.x & 63) == 0 && s > 0) atomicMax(mx, s);
 }
-// one lane per coarse row: gather (agg(col), val) of all member rows, insertion-sort by
-// coarse column (stable: fine order i↑, j↑ inside a key), then reduce equal keys in place.
-__global__ void galerkin_fill_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg /*column map, size = cols of A*/,
-                                     const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
-                                     const int *__restrict__ offs, int *__restrict__ scol, double *__restrict__ sval, int *__restrict__ uniq) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+template <int CAP, int TBK, bool FILL>
+__global__ __launch_bounds__(TBK) void galerkin_lds_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg /*column map, size = cols of A*/,
+                                                           const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+                                                           const int *__restrict__ crowptr, int *__restrict__ uniq, int *__restrict__ ccol, double *__restrict__ cval) {
+  __shared__ int keys[CAP * TBK];
+  __shared__ double vals[FILL ? CAP * TBK : 1];
+  const int c = blockIdx.x * TBK + threadIdx.x, t = threadIdx.x;
   if (c > nc) return;
-  if (c == nc) { uniq[c] = 0; return; }
-  const int base = offs[c];
-  int cnt = 0;
+  if (c == nc) { if (!FILL) uniq[c] = 0; return; }
   const int m0 = cptr ? cptr[c] : c, m1 = cptr ? cptr[c + 1] : c + 1;
+  int cnt = 0;
+  bool spilled = false;      // more than CAP distinct columns: continue in global memory
+  const int dst = FILL ? crowptr[c] : 0;
+  int extra = 0;             // count pass, spilled: distinct columns beyond the CAP held in LDS
   for (int m = m0; m < m1; ++m) {
-    int i = cptr ? members[m] : m;
+    const int i = cptr ? members[m] : m;
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-      int a = agg[col[k]];
+      const int a = agg[col[k]];
       if (a < 0) continue;
-      double v = val[k];
-      int b = base + cnt - 1;
-      while (b >= base && scol[b] > a) { scol[b + 1] = scol[b]; sval[b + 1] = sval[b]; --b; }
-      scol[b + 1] = a; sval[b + 1] = v;
-      ++cnt;
+      if (!spilled) {
+        int b = cnt - 1;
+        while (b >= 0 && keys[b * TBK + t] > a) --b;
+        if (b >= 0 && keys[b * TBK + t] == a) { if (FILL) vals[b * TBK + t] += val[k]; continue; }
+        if (cnt < CAP) {
+          for (int q = cnt - 1; q > b; --q) { keys[(q + 1) * TBK + t] = keys[q * TBK + t]; if (FILL) vals[(q + 1) * TBK + t] = vals[q * TBK + t]; }
+          keys[(b + 1) * TBK + t] = a; if (FILL) vals[(b + 1) * TBK + t] = val[k];
+          ++cnt;
+          continue;
+        }
+        spilled = true;
+        if (FILL) { for (int q = 0; q < cnt; ++q) { ccol[dst + q] = keys[q * TBK + t]; cval[dst + q] = vals[q * TBK + t]; } }
+      }
+      if (FILL) {            // the row's output segment (its length is the distinct count of the count pass): same insert-or-add there
+        int b = cnt - 1;
+        while (b >= 0 && ccol[dst + b] > a) --b;
+        if (b >= 0 && ccol[dst + b] == a) { cval[dst + b] += val[k]; continue; }
+        for (int q = cnt - 1; q > b; --q) { ccol[dst + q + 1] = ccol[dst + q]; cval[dst + q + 1] = cval[dst + q]; }
+        ccol[dst + b + 1] = a; cval[dst + b + 1] = val[k];
+        ++cnt;
+      } else {               // is this column new?  not among the CAP columns in LDS and not among the earlier entries (walked again)
+        bool seen = false;
+        for (int q = 0; q < CAP && !seen; ++q) seen = keys[q * TBK + t] == a;
+        for (int mm = m0; mm <= m && !seen; ++mm) {
+          const int ii = cptr ? members[mm] : mm;
+          const int ke = mm == m ? k : rowptr[ii + 1];
+          for (int kk = rowptr[ii]; kk < ke && !seen; ++kk) seen = agg[col[kk]] == a;
+        }
+        if (!seen) ++extra;
+      }
     }
   }
-  int w = 0;
-  for (int r = 0; r < cnt;) {
-    int key = scol[base + r]; double s = sval[base + r]; ++r;
-    while (r < cnt && scol[base + r] == key) { s += sval[base + r]; ++r; }
-    scol[base + w] = key; sval[base + w] = s; ++w;
-  }
-  uniq[c] = w;
-}
-__global__ void galerkin_copy_kernel(int nc, const int *__restrict__ offs, const int *__restrict__ crowptr, const int *__restrict__ scol,
-                                     const double *__restrict__ sval, int *__restrict__ ccol, double *__restrict__ cval) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nc) return;
-  int src = offs[c], dst = crowptr[c], len = crowptr[c + 1] - dst;
-  for (int q = 0; q < len; ++q) { ccol[dst + q] = scol[src + q]; cval[dst + q] = sval[src + q]; }
+  if (!FILL) { uniq[c] = cnt + extra; return; }
+  if (!spilled) for (int q = 0; q < cnt; ++q) { ccol[dst + q] = keys[q * TBK + t]; cval[dst + q] = vals[q * TBK + t]; }
 }
 
 // ------------------------------------------------------------------ pairwise aggregation
@@ -450,17 +471,20 @@ int k_xfer_from_csr(const mgs_csr *P, mgs_xfer **out) {
 // rows first, then halo slots for row shards); ncols_out = number of coarse columns.
 static int galerkin_core(const mgs_csr *A, int nc, const int *cptr, const int *members, const int *colmap, int ncols_out, mgs_csr **out) {
   mgs_ctx *ctx = A->ctx;
-  DevBuf ub, uniq, scol, sval;
-  MGS_TRY(dalloc<int>(ctx, ub, (size_t)nc + 1));
+  DevBuf uniq, mx;
   MGS_TRY(dalloc<int>(ctx, uniq, (size_t)nc + 1));
-  hipLaunchKernelGGL(galerkin_ub_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, A->rowptr, ub.as<int>());
-  MGS_TRY(scan_rec(ctx, ub.as<int>(), ub.as<int>(), (int64_t)nc + 1));
-  int tot = 0;
-  MGS_HIP(ctx, hipMemcpyAsync(&tot, ub.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MGS_TRY(dalloc<int>(ctx, mx, 1));
+  MGS_HIP(ctx, hipMemsetAsync(mx.p, 0, sizeof(int), ctx->stream));
+  if (nc) hipLaunchKernelGGL(galerkin_maxub_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, A->rowptr, mx.as<int>());
+  int maxub = 0;
+  MGS_HIP(ctx, hipMemcpyAsync(&maxub, mx.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MGS_TRY(dalloc<int>(ctx, scol, (size_t)tot));
-  MGS_TRY(dalloc<double>(ctx, sval, (size_t)tot));
-  hipLaunchKernelGGL(galerkin_fill_kernel, dim3(mgs_grid(nc + 1, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, colmap, A->rowptr, A->col, A->val, ub.as<int>(), scol.as<int>(), sval.as<double>(), uniq.as<int>());
+  // slots per lane from the longest gathered row (an upper bound of its distinct columns); beyond 64 the long rows spill
+  const int cap = maxub <= 16 ? 16 : (maxub <= 32 ? 32 : 64);
+#define GAL_(CAPV, TBV, FILLV, CRP, CC, CV) hipLaunchKernelGGL((galerkin_lds_kernel<CAPV, TBV, FILLV>), dim3(mgs_grid(nc + 1, TBV)), dim3(TBV), 0, ctx->stream, nc, cptr, members, \
+                                                              colmap, A->rowptr, A->col, A->val, CRP, uniq.as<int>(), CC, CV)
+  if (cap == 16) GAL_(16, 256, false, nullptr, nullptr, nullptr); else if (cap == 32) GAL_(32, 128, false, nullptr, nullptr, nullptr); else GAL_(64, 64, false, nullptr, nullptr, nullptr);
+  MGS_HIP(ctx, hipGetLastError());
   MGS_TRY(scan_rec(ctx, uniq.as<int>(), uniq.as<int>(), (int64_t)nc + 1));
   int nnzc = 0;
   MGS_HIP(ctx, hipMemcpyAsync(&nnzc, uniq.as<int>() + nc, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -468,7 +492,8 @@ static int galerkin_core(const mgs_csr *A, int nc, const int *cptr, const int *m
   mgs_csr *C = nullptr;
   MGS_TRY(mgs_csr_alloc(ctx, nc, ncols_out, nnzc, &C));
   MGS_HIP(ctx, hipMemcpyAsync(C->rowptr, uniq.p, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToDevice, ctx->stream));
-  if (nc) hipLaunchKernelGGL(galerkin_copy_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, ub.as<int>(), C->rowptr, scol.as<int>(), sval.as<double>(), C->col, C->val);
+  if (nc) { if (cap == 16) GAL_(16, 256, true, C->rowptr, C->col, C->val); else if (cap == 32) GAL_(32, 128, true, C->rowptr, C->col, C->val); else GAL_(64, 64, true, C->rowptr, C->col, C->val); }
+#undef GAL_
   MGS_HIP(ctx, hipGetLastError());
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MGS_TRY(mgs_plan_csr(C));
