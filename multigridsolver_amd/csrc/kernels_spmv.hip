@@ -1372,14 +1372,25 @@ int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_grou
     // greedy union of row blocks along their most frequent links, groups of at most GRP_BLOCKS blocks (deterministic: links
     // sorted by count, then by block pair)
     struct Link { int cnt, a, b; };
-    std::vector<Link> links;
-    for (int b = 0; b < nblocks; ++b)
+    std::vector<Link> raw, links;
+    for (int b = 0; b < nblocks; ++b) {
+      Link mine[GRP_SLOTS]; int nm = 0;
       for (int sl = 0; sl < GRP_SLOTS; ++sl) {
         const int k = hk[(size_t)b * GRP_SLOTS + sl], c = hn[(size_t)b * GRP_SLOTS + sl];
         // option group_min_link: only links that carry a share of the block's aggregates (default 1 = every link; see mgs_internal.hpp)
-        if (k > b && k < nblocks && c >= ctx->opt_group_min_link) links.push_back({c, b, k});
+        if (k > b && k < nblocks && c >= ctx->opt_group_min_link) mine[nm++] = {c, b, k};
       }
-    std::sort(links.begin(), links.end(), [](const Link &p, const Link &q) { return p.cnt != q.cnt ? p.cnt > q.cnt : (p.a != q.a ? p.a < q.a : p.b < q.b); });
+      std::sort(mine, mine + nm, [](const Link &p, const Link &q) { return p.b < q.b; });
+      for (int q = 0; q < nm; ++q) raw.push_back(mine[q]);
+    }
+    {   // order: count descending, then (a, b) ascending — raw is already (a, b)-ascending, so a stable counting sort by count does it
+        // (a count is at most the 256 aggregates that can start in one row block; half a million blocks at 512³: no comparison sort)
+      std::vector<size_t> start((size_t)RB + 2, 0);
+      for (const Link &l : raw) ++start[(size_t)(RB - std::min(l.cnt, RB)) + 1];
+      for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+      links.resize(raw.size());
+      for (const Link &l : raw) links[start[(size_t)(RB - std::min(l.cnt, RB))]++] = l;
+    }
     std::vector<int> parent((size_t)nblocks), gsize((size_t)nblocks, 1);
     for (int b = 0; b < nblocks; ++b) parent[b] = b;
     auto find = [&](int v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };

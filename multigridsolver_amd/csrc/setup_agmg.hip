@@ -138,7 +138,8 @@ __global__ void galerkin_maxub_kernel(int nc, const int *__restrict__ cptr, cons
   if (c < nc && !cptr) s = rowptr[c + 1] - rowptr[c];
   else if (c < nc) for (int k = cptr[c]; k < cptr[c + 1]; ++k) { int i = members[k]; s += rowptr[i + 1] - rowptr[i]; }
   for (int off = 32; off > 0; off >>= 1) s = max(s, __shfl_down(s, off));
-  if ((threadIdx.x & 63) == 0 && s > 0) atomicMax(mx, s);
+  // (one address for the whole launch: only a wave that would raise the maximum goes to the atomic unit)
+  if ((threadIdx.x & 63) == 0 && s > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, s);
 }
 template <int CAP, int TBK, bool FILL>
 __global__ __launch_bounds__(TBK) void galerkin_lds_kernel(int nc, const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg /*column map, size = cols of A*/,
