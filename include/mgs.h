@@ -340,7 +340,10 @@ int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]);
  * "graph", "strip", "fuse", "nt_store" (streaming stores, measured neutral), "valcode" (opt-in: pattern tuples carry the values too, set before
  * mgs_csr_optimize / the hierarchy is built; pays only where coefficients repeat), "rowcode" (pattern-coded index, default 1), "split_min_rows" (row shards: smallest level that
  * overlaps its halo exchange with interior row blocks, default 400000), "fuse_operands" (setup-time operands of the fused cycle passes,
- * +12 B of HBM per matrix entry; default 1), "lds_pad", "blkptr".  Unknown key: MGS_ERR_INVALID. */
+ * +12 B of HBM per matrix entry; default 1), "merge_ap" (fused post pass on A·P with the entries of one aggregate summed at setup instead of A with
+ * aggregate-mapped columns; default 1; equal to rounding, not bit for bit), "fuse_restrict" / "group_blocks" / "group_stray_pct" / "group_min_blocks" / "group_strip"
+ * (grouped pre pass: restriction inside the pre-smoothing pass, see mgs_hier_group_info), "diag_from_values", "fuse_dots", "lds_pad", "blkptr".
+ * Unknown key: MGS_ERR_INVALID. */
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

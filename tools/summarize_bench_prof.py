@@ -17,6 +17,16 @@ with open(os.path.join(REPO, "profiles", f"{tag}_bench_prof.md"), "w") as f:
     f.write("Fine-level (512^3) dispatches of the row-block kernels in the trace:\n\n| kernel | launches | avg us | min us | max us |\n|---|---|---|---|---|\n")
     for k, v in sorted(byk.items()):
         f.write(f"| {k} | {len(v)} | {sum(v)/len(v)/1e3:.1f} | {min(v)/1e3:.1f} | {max(v)/1e3:.1f} |\n")
+    # the launches bench.py times for the roofline: the first 3 warm-up + kernel_reps launches of the coded SpMV kernel in the trace (start
+    # order); the later ones belong to the Krylov solves (BiCGSTAB's carry the fused dot epilogue and read other vectors)
+    spmv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows
+                  if r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").startswith("csr_rowblock_coded_kernel<0, 7, false, false>"))
+    reps = 20
+    leg = [d for _, d in spmv[3:3 + reps]]
+    if leg:
+        f.write(f"\nRoofline leg of the coded SpMV kernel (launches 4..{3 + len(leg)} of it in start order = the {len(leg)} launches between bench.py's HIP events): "
+                f"avg {sum(leg)/len(leg)/1e3:.1f} us (min {min(leg)/1e3:.1f}, max {max(leg)/1e3:.1f}) against {bench['roofline']['ms_per_launch'] * 1e3:.1f} us by HIP events; "
+                f"the remaining {len(spmv) - 3 - len(leg)} launches are the solvers' products.\n")
     f.write("\n`csr_rowblock_coded_kernel<0, ...>` = SpMV with the pattern-coded index (the roofline kernel; also launched twice per BiCGSTAB iteration), "
             "`<1>` residual (= fused pre pass on the scaled values; in the cycle itself the fine level runs `csr_group_pre_kernel`: pre pass + restriction in one kernel), `<2>` Jacobi, `<5>` fused post pass (template tail `<…, HALO, VAL>`: `VAL = true` rows belong to the opt-in value-pattern leg, not to the headline); `csr_rowblock_slice_kernel<0>` = plain CSR SpMV "
             "(timed once for comparison, `rowcode` = 0), `csr_rowblock_fused_kernel<3>/<4>` = gather forms of the fused passes (unfused/A-B legs only).\n\nTop of the --stats table (all sizes mixed):\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
