@@ -826,6 +826,41 @@ def test_random_aggregations_and_graph_laplacians(ctx, mg, orc):
         assert np.linalg.norm(Ao.residual(x.numpy(), b_np)) / np.linalg.norm(b_np) <= 2e-10
 
 
+def test_galerkin_and_merged_operand_with_long_rows(ctx, mg, orc):
+    """Galerkin product and A·P on rows with far more distinct coarse columns than the 16/32/64 LDS slots of a lane (the spill path of
+    galerkin_lds_kernel: count pass by re-walking, fill pass in the row's own output segment): banded operator + a few dense rows and columns,
+    aggregates of three; pattern exact, values ≤1e-13, and the cycle built on that P (post pass on A·P with long rows) vs the oracle"""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(5)
+    n = 4000
+    B = sps.diags([-1.0, -1.0, -0.5, -0.5], [1, -1, 7, -7], shape=(n, n)).tolil()
+    dense = [3, 1000, 1001, 2500, 3998]
+    for d in dense:
+        js = rng.choice(n, 500, replace=False); js = js[js != d]
+        w = -rng.uniform(0.01, 0.02, js.size)
+        B[d, js] = w; B[js, d] = w
+    B = B.tocsr(); B.setdiag(0); B.eliminate_zeros()
+    A_sp = (sps.diags(-np.asarray(B.sum(axis=1)).ravel() + 0.1) + B).tocsr(); A_sp.sort_indices()
+    Ao = orc.Csr.from_scipy(A_sp); A = dev(ctx, Ao)
+    agg = (np.arange(n) // 3).astype(np.int32); nc = int(agg.max()) + 1
+    Po = orc.Csr.from_scipy(sps.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, nc)))
+    T = mg.Xfer.from_csr(dev(ctx, Po))
+    Ac = A.galerkin(T); rp, ci, v = Ac.download(); Aco = Ao.galerkin(Po)
+    assert np.diff(rp).max() > 64                                    # the spill path ran
+    assert np.array_equal(rp, Aco.rowptr) and np.array_equal(ci, Aco.col)
+    assert np.max(np.abs(v - Aco.val)) <= 1e-13 * max(1.0, np.abs(Aco.val).max())
+    h = mg.Hierarchy(A, 0.6, 1, 1).push_P(dev(ctx, Po)).finalize()
+    b_np = rng.standard_normal(n)
+    ho = orc.Hier(Ao, [Po], omega=0.6, nu1=1, nu2=1)
+    xg = h.vcycle(ctx.vec(b_np)).numpy()
+    assert rel(xg, ho.vcycle(b_np)) <= 1e-10
+    try:
+        ctx.set_option("merge_ap", 0); xm = h.vcycle(ctx.vec(b_np)).numpy()
+    finally:
+        ctx.set_option("merge_ap", 1)
+    assert rel(xg, xm) <= 1e-12
+
+
 def test_setup_driver_and_reference_crosscheck(orc, inputs, tmp_path):
     """mgs_agmg = the reference's setup CLI (src/CPU_C++/main.cpp:153-239, src/GPU_CUDAC++/main.cu:18-297): writes
     <name>promatrix_gpu.mtx.  The file must equal (sha256) the one that was fed to the REAL reference's bicg in
