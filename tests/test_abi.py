@@ -105,3 +105,73 @@ def test_loader_property_random_files(orc, tmp_path):
         assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(v, ref.data)
 
     run()
+
+
+@pytest.mark.parametrize("threads", ["1", "2", "5", "16"])
+def test_loader_parallel_pieces_token_contract(orc, tmp_path, monkeypatch, threads):
+    """the loader cuts the file into one piece per thread at whitespace; the contract stays token based (MatrixIO.cpp:23-27 reads
+    with `>>`): triples may span lines, any entry order, trailing tokens after the L-th triple are never read.  Library loader ==
+    oracle loader for every piece count, values bit for bit (17-digit decimals go through strtod, short ones through the exact
+    fast path)."""
+    import multigridsolver_amd as mg
+    monkeypatch.setenv("MGS_IO_THREADS", threads)
+    rng = np.random.default_rng(int(threads))
+    M, N = 37, 41
+    cells = rng.permutation(M * N)[:600]
+    vals = rng.standard_normal(600) * 10.0 ** rng.integers(-30, 30, 600)
+    vals[::7] = np.round(vals[::7], 3)
+    vals[5] = 0.0; vals[6] = -0.0; vals[8] = 5e-324; vals[9] = 1.7976931348623157e308; vals[10] = 123456789012345678.0
+    seps = [" ", "\n", "\t", "  \n ", "\r\n", " \t"]
+    p = tmp_path / "t.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general \n% x\n")
+        f.write(f"{M} {N}\n{len(cells)}")
+        for q, (c, v) in enumerate(zip(cells, vals)):
+            txt = repr(float(v)) if q % 3 else ("%.6g" % v)
+            f.write(f"{seps[q % 6]}{c // N + 1}{seps[(q + 1) % 6]}{c % N + 1}{seps[(q + 2) % 6]}{txt}")
+        f.write("\n9999 9999 not-a-number trailing tokens are never read\n")
+    rows, cols, rp, ci, v = mg.read_mtx(str(p))
+    o = orc.Csr.read(str(p))
+    assert (rows, cols) == (M, N) == o.shape
+    assert np.array_equal(rp, o.rowptr) and np.array_equal(ci, o.col)
+    assert np.array_equal(v.view(np.int64), o.val.view(np.int64))          # bits, so that -0.0 and the denormal count
+    # row-major files (what every writer emits) take the no-scatter path: same arrays
+    a = tmp_path / "a.mtx"
+    mg.write_mtx(str(a), rows, cols, rp, ci, v)
+    r2 = mg.read_mtx(str(a))
+    o2 = orc.Csr.read(str(a))
+    assert np.array_equal(r2[2], o2.rowptr) and np.array_equal(r2[3], o2.col) and np.array_equal(r2[4].view(np.int64), o2.val.view(np.int64))
+    b = tmp_path / "b.mtx"
+    o.write(str(b))
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_loader_rejects_what_the_stream_reader_rejects(tmp_path, monkeypatch, threads):
+    """`istream >> int/double` fails on these tokens (libstdc++ num_get: no inf/nan/hex, overflow sets failbit); the reference then
+    runs on garbage, this loader returns MGS_ERR_IO naming the first offending entry"""
+    import multigridsolver_amd as mg
+    monkeypatch.setenv("MGS_IO_THREADS", threads)
+    body = "".join(f"{i + 1} {i + 1} {i}.5\n" for i in range(50))
+    for bad, where in [("3 3 nan\n", "entry 51"), ("3 3 0x10\n", "entry 51"), ("3 3 1e999\n", "entry 51"), ("3 3 1e\n", "entry 51"),
+                       ("3.0 3 1\n", "entry 51"), ("0 3 1\n", "entry 51"), ("3 51 1\n", "entry 51"), ("3 3 1,5\n", "entry 51")]:
+        p = tmp_path / "bad.mtx"
+        p.write_text("%h\n50 50 52\n" + body + bad + "4 5 1.0\n")
+        with pytest.raises(mg.MgsError) as e:
+            mg.read_mtx(str(p))
+        assert where in str(e.value), str(e.value)
+    p = tmp_path / "dup.mtx"
+    p.write_text("%h\n50 50 52\n" + body + "7 9 1.0\n7 9 2.0\n")
+    with pytest.raises(mg.MgsError) as e:
+        mg.read_mtx(str(p))
+    assert "duplicate entry (7,9)" in str(e.value)
+    for hdr in ["50 50\n", "50 x 3\n", "-1 5 0\n", "\n% late comment\n5 5 0\n", ""]:
+        p = tmp_path / "hdr.mtx"
+        p.write_text("%h\n" + hdr)
+        with pytest.raises(mg.MgsError) as e:
+            mg.read_mtx(str(p))
+        assert "bad size line" in str(e.value)
+    p = tmp_path / "empty.mtx"
+    p.write_text("%h\n4 6 0\n")
+    rows, cols, rp, ci, v = mg.read_mtx(str(p))
+    assert (rows, cols) == (4, 6) and rp.tolist() == [0] * 5 and len(ci) == 0 and len(v) == 0
