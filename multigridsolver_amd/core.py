@@ -238,6 +238,14 @@ class Vec:
     def nrm2(self):
         out = C.c_double(); check(lib().mgs_nrm2(self.h, C.byref(out)), self.ctx.h); return out.value
 
+    def axpby(self, a, x, b):
+        """self = a·x + b·self"""
+        check(lib().mgs_axpby(float(a), x.h, float(b), self.h), self.ctx.h); return self
+
+    def axpbypcz(self, a, x, b, y, c):
+        """self = a·x + b·y + c·self"""
+        check(lib().mgs_axpbypcz(float(a), x.h, float(b), y.h, float(c), self.h), self.ctx.h); return self
+
 
 class Xfer:
     """Prolongation P (+ restriction Pᵀ) — reference bicg.cpp:32,48."""

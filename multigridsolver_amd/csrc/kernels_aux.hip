@@ -59,6 +59,45 @@ __global__ void axpbypcz_kernel(int64_t n, double a, const double *__restrict__ 
   else { for (; i < n; i += stride) z[i] = a * x[i] + b * y[i] + c * z[i]; }
 }
 
+// 16-byte forms of the two update kernels (option blas1_vec, default on; used when every operand is 16-byte aligned): each lane
+// moves a pair of doubles per load/store and the loop is unrolled so that several loads per stream are in flight per wave — the
+// 8-byte grid-stride loops above stop at ≈ 4 TB/s on this part, a pure stream wants ≥ 16 B per lane (MI355X_MICROARCH.md, HBM:
+// 6.3 TB/s for a float4 copy).  Element i is computed by the same expression as above, so the results have the same bits.
+typedef double vd2 __attribute__((ext_vector_type(2)));
+template <bool HASB>
+__global__ __launch_bounds__(TB) void axpby_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+  const int64_t n2 = n >> 1;
+  const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
+  vd2 *__restrict__ yv = reinterpret_cast<vd2 *>(y);
+  const int64_t stride = (int64_t)gridDim.x * TB;
+#pragma unroll 4
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+    const vd2 p = xv[i]; vd2 q;
+    if (HASB) { const vd2 o = yv[i]; q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y; }
+    else { q.x = a * p.x; q.y = a * p.y; }
+    yv[i] = q;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = HASB ? a * x[n - 1] + b * y[n - 1] : a * x[n - 1];
+}
+template <bool HASC>
+__global__ __launch_bounds__(TB) void axpbypcz_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b,
+                                                          const double *__restrict__ y, double c, double *__restrict__ z) {
+  const int64_t n2 = n >> 1;
+  const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
+  const vd2 *__restrict__ yv = reinterpret_cast<const vd2 *>(y);
+  vd2 *__restrict__ zv = reinterpret_cast<vd2 *>(z);
+  const int64_t stride = (int64_t)gridDim.x * TB;
+#pragma unroll 4
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+    const vd2 p = xv[i], o = yv[i]; vd2 q;
+    if (HASC) { const vd2 w = zv[i]; q.x = a * p.x + b * o.x + c * w.x; q.y = a * p.y + b * o.y + c * w.y; }
+    else { q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y; }
+    zv[i] = q;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = HASC ? a * x[n - 1] + b * y[n - 1] + c * z[n - 1] : a * x[n - 1] + b * y[n - 1];
+}
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // first damped-Jacobi sweep from x = 0: x = 0 + (ωD⁻¹)(b − A·0) = (ω·dinv_i)·b_i, bit-identical
 __global__ void jacobi_zero_kernel(int n, double omega, const double *__restrict__ dinv, const double *__restrict__ b, double *__restrict__ x) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,7 +173,7 @@ __global__ void gather_pe_kernel(const double *__restrict__ ec, const int *__res
 // ------------------------------------------------------------------ reductions
 // Two-stage deterministic dot: fixed grid of partials (independent of scheduling), then one
 // block folds them in index order.  reference bicg.cpp:64-72 (dot/norm helpers).
-constexpr int DOT_BLOCKS = 1024;
+constexpr int DOT_BLOCKS = 4096;   // partial slots (a pair kernel uses half of them per sum): 8 workgroups per CU on 256 CUs
 __global__ __launch_bounds__(TB) void dot_partial_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part) {
   __shared__ double sh[TB / 64];
   double s = 0.0;
@@ -198,6 +237,42 @@ __global__ __launch_bounds__(TB) void update_dot2_partial_kernel(int64_t n, doub
     z[i] = zi;
     s0 += zi * zi;
     if (w) s1 += w[i] * zi;
+  }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
+// 16-byte form of the kernel above (same per-element expression; the partial sums associate differently: lane t adds its pairs
+// x then y, a fixed order that does not depend on scheduling)
+template <bool HASW>
+__global__ __launch_bounds__(TB) void update_dot2_partial_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
+                                                                     double *__restrict__ z, const double *__restrict__ w, double *__restrict__ part) {
+  __shared__ double sh[2][TB / 64];
+  const int64_t n2 = n >> 1;
+  const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
+  const vd2 *__restrict__ yv = reinterpret_cast<const vd2 *>(y);
+  const vd2 *__restrict__ wv = reinterpret_cast<const vd2 *>(w);
+  vd2 *__restrict__ zv = reinterpret_cast<vd2 *>(z);
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * TB;
+#pragma unroll 4
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+    const vd2 p = xv[i], o = yv[i]; vd2 q;
+    q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y;
+    zv[i] = q;
+    s0 += q.x * q.x; s0 += q.y * q.y;
+    if (HASW) { const vd2 ww = wv[i]; s1 += ww.x * q.x; s1 += ww.y * q.y; }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double zi = a * x[n - 1] + b * y[n - 1];
+    z[n - 1] = zi; s0 += zi * zi;
+    if (HASW) s1 += w[n - 1] * zi;
   }
   for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
   if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
@@ -435,11 +510,21 @@ int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off) {
   return MGS_OK;
 }
 int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
+  if (n && ctx->opt_blas1_vec && al16(x) && al16(y)) {
+    const dim3 g(grid_cap((n + 1) / 2, ctx->n_cu));
+    if (b == 0.0) hipLaunchKernelGGL(axpby_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y);
+    else hipLaunchKernelGGL(axpby_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y);
+  } else
   if (n) hipLaunchKernelGGL(axpby_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
 int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z) {
+  if (n && ctx->opt_blas1_vec && al16(x) && al16(y) && al16(z)) {
+    const dim3 g(grid_cap((n + 1) / 2, ctx->n_cu));
+    if (c == 0.0) hipLaunchKernelGGL(axpbypcz_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
+    else hipLaunchKernelGGL(axpbypcz_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
+  } else
   if (n) hipLaunchKernelGGL(axpbypcz_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
@@ -505,7 +590,7 @@ __global__ __launch_bounds__(TB) void dot2_mid_kernel(int nb, int chunk, const d
 }
 int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part, double *out_host2) {
   if (nb > 4096) {          // three stages: row-block partials → 256 chunk sums (in red_dev) → the pair
-    const int groups = DOT_BLOCKS / 4, chunk = (nb + groups - 1) / groups;
+    const int groups = 256, chunk = (nb + groups - 1) / groups;
     hipLaunchKernelGGL(dot2_mid_kernel, dim3(groups), dim3(TB), 0, ctx->stream, nb, chunk, part, ctx->red_dev);
     part = ctx->red_dev; nb = groups;
   }
@@ -541,6 +626,13 @@ int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, 
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
   if (nb < 1) nb = 1;
+  if (ctx->opt_blas1_vec && al16(x) && al16(y) && al16(z) && al16(w)) {
+    nb = (int)(((n + 1) / 2 + TB - 1) / TB);
+    if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
+    if (nb < 1) nb = 1;
+    if (w) hipLaunchKernelGGL(update_dot2_partial_vec_kernel<true>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
+    else hipLaunchKernelGGL(update_dot2_partial_vec_kernel<false>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
+  } else
   hipLaunchKernelGGL(update_dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));

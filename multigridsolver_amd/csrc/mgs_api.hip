@@ -82,7 +82,7 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
   else { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return mgs_fail(nullptr, MGS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-  c->red_cap = 2048;
+  c->red_cap = 4096 + 64;    // DOT_BLOCKS partials + the folded results (kernels_aux.hip)
   if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16) != hipSuccess) {
     delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
   }
@@ -145,6 +145,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "group_min_blocks") ctx->opt_group_min_blocks = value;
   else if (k == "native_graph") ctx->opt_native_graph = value;
   else if (k == "native_overlap") ctx->opt_native_overlap = value;
+  else if (k == "blas1_vec") ctx->opt_blas1_vec = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;

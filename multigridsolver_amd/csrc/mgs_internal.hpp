@@ -52,6 +52,7 @@ struct mgs_ctx {
   int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/ab_group2.py): 4-block groups 6.21 ms per cycle,
                                // pairs 6.34 ms, separate kernels 6.64 ms
   int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
+  int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:
                               // a graph with cross-stream edges costs 0.48 ms of host time per launch and 1.219 vs 1.155 ms per cycle — off by default)

@@ -356,6 +356,51 @@ def test_blas1(ctx, mg, orc):
     assert np.array_equal(h1[500:], h2) and 0 <= h1.min() and h1.max() < 1 and abs(h1.mean() - 0.5) < 0.05
 
 
+def test_blas1_update_kernels_16_byte_forms(ctx, mg, orc):
+    """axpby / axpbypcz and the update fused with two inner products (BiCGSTAB's s = r − αv, r = s − ωt, bicg.cpp:104,109,119-120)
+    in their 16-byte forms (option blas1_vec): every element has the bits of the 8-byte loop and of numpy with unfused mul/add;
+    odd lengths take the scalar tail, operands that are only 8-byte aligned (wrapped views) fall back to the 8-byte kernel."""
+    rng = np.random.default_rng(7)
+    try:
+        for n in (1, 2, 255, 256, 100003, 2 * 256 * 256 * 9 + 1):
+            x, y, z = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+            got = {}
+            for opt in (1, 0):
+                ctx.set_option("blas1_vec", opt)
+                vx, vy, vz = ctx.vec(x), ctx.vec(y), ctx.vec(z)
+                r1 = vy.axpby(0.3, vx, -1.7).numpy()
+                r2 = ctx.vec(y).axpby(2.5, vx, 0.0).numpy()
+                r3 = vz.axpbypcz(0.3, vx, -1.7, ctx.vec(y), 0.9).numpy()
+                r4 = ctx.vec(z).axpbypcz(0.3, vx, -1.7, ctx.vec(y), 0.0).numpy()
+                got[opt] = (r1, r2, r3, r4)
+            ref = (0.3 * x + -1.7 * y, 2.5 * x, 0.3 * x + -1.7 * y + 0.9 * z, 0.3 * x + -1.7 * y)
+            for q in range(4):
+                assert np.array_equal(got[1][q], got[0][q]) and np.array_equal(got[1][q], ref[q]), (n, q)
+        # views that start on an odd element: the launcher must not take the 16-byte path
+        ctx.set_option("blas1_vec", 1)
+        n = 4099
+        x, y = rng.standard_normal(n + 1), rng.standard_normal(n + 1)
+        bx, by = ctx.vec(x), ctx.vec(y)
+        wx, wy = mg.Vec.wrap(ctx, bx.ptr + 8, n), mg.Vec.wrap(ctx, by.ptr + 8, n)
+        wy.axpby(0.5, wx, 0.25)
+        out = by.numpy()
+        assert out[0] == y[0] and np.array_equal(out[1:], 0.5 * x[1:] + 0.25 * y[1:])
+        # the fused update + dots inside the solver: same iterates to rounding with either form (the partial sums associate differently)
+        A_o = orc.poisson2d(40)
+        A = dev(ctx, A_o)
+        b = ctx.vec(orc.rand_rhs(A_o.shape[0]))
+        res = {}
+        for opt in (1, 0):
+            ctx.set_option("blas1_vec", opt)
+            xs = ctx.vec(A_o.shape[0])
+            st, it, tol = mg.bicgstab(A, xs, b, None, 500, 1e-12)
+            assert st == 0
+            res[opt] = (it, xs.numpy())
+        assert abs(res[1][0] - res[0][0]) <= 0.05 * res[0][0] and rel(res[1][1], res[0][1]) <= 1e-8     # unpreconditioned: the count moves with the last bits of the dots
+    finally:
+        ctx.set_option("blas1_vec", 1)
+
+
 def test_device_agmg_hierarchy(ctx, mg, orc, inputs, golden):
     """config 3: hierarchy built on device.  The reference judges aggregate quality by BiCGSTAB
     iteration count (results.txt:48-51); the device matching is deterministic."""
