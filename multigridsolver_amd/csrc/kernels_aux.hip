@@ -2,6 +2,9 @@
 // on-device operator generators, halo pack.  gfx950 only.
 #include "mgs_internal.hpp"
 
+#include <chrono>
+#include <time.h>
+
 namespace {
 constexpr int TB = 256;
 
@@ -64,8 +67,13 @@ __global__ void axpbypcz_kernel(int64_t n, double a, const double *__restrict__ 
 // 8-byte grid-stride loops above stop at ≈ 4 TB/s on this part, a pure stream wants ≥ 16 B per lane (MI355X_MICROARCH.md, HBM:
 // 6.3 TB/s for a float4 copy).  Element i is computed by the same expression as above, so the results have the same bits.
 typedef double vd2 __attribute__((ext_vector_type(2)));
+// streaming store (the instruction spelled out: see st_stream in kernels_spmv.hip); nothing here reads back what it stored
+__device__ __forceinline__ void st2(vd2 *p, vd2 v, bool nt) {
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else *p = v;
+}
 template <bool HASB>
-__global__ __launch_bounds__(TB) void axpby_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+__global__ __launch_bounds__(TB) void axpby_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y, int nts) {
   const int64_t n2 = n >> 1;
   const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
   vd2 *__restrict__ yv = reinterpret_cast<vd2 *>(y);
@@ -75,13 +83,13 @@ __global__ __launch_bounds__(TB) void axpby_vec_kernel(int64_t n, double a, cons
     const vd2 p = xv[i]; vd2 q;
     if (HASB) { const vd2 o = yv[i]; q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y; }
     else { q.x = a * p.x; q.y = a * p.y; }
-    yv[i] = q;
+    st2(yv + i, q, nts != 0);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = HASB ? a * x[n - 1] + b * y[n - 1] : a * x[n - 1];
 }
 template <bool HASC>
 __global__ __launch_bounds__(TB) void axpbypcz_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b,
-                                                          const double *__restrict__ y, double c, double *__restrict__ z) {
+                                                          const double *__restrict__ y, double c, double *__restrict__ z, int nts) {
   const int64_t n2 = n >> 1;
   const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
   const vd2 *__restrict__ yv = reinterpret_cast<const vd2 *>(y);
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(TB) void axpbypcz_vec_kernel(int64_t n, double a, c
     const vd2 p = xv[i], o = yv[i]; vd2 q;
     if (HASC) { const vd2 w = zv[i]; q.x = a * p.x + b * o.x + c * w.x; q.y = a * p.y + b * o.y + c * w.y; }
     else { q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y; }
-    zv[i] = q;
+    st2(zv + i, q, nts != 0);
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = HASC ? a * x[n - 1] + b * y[n - 1] + c * z[n - 1] : a * x[n - 1] + b * y[n - 1];
 }
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(TB) void update_dot2_partial_kernel(int64_t n, doub
 // x then y, a fixed order that does not depend on scheduling)
 template <bool HASW>
 __global__ __launch_bounds__(TB) void update_dot2_partial_vec_kernel(int64_t n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
-                                                                     double *__restrict__ z, const double *__restrict__ w, double *__restrict__ part) {
+                                                                     double *__restrict__ z, const double *__restrict__ w, double *__restrict__ part, int nts) {
   __shared__ double sh[2][TB / 64];
   const int64_t n2 = n >> 1;
   const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(TB) void update_dot2_partial_vec_kernel(int64_t n, 
   for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
     const vd2 p = xv[i], o = yv[i]; vd2 q;
     q.x = a * p.x + b * o.x; q.y = a * p.y + b * o.y;
-    zv[i] = q;
+    st2(zv + i, q, nts != 0);
     s0 += q.x * q.x; s0 += q.y * q.y;
     if (HASW) { const vd2 ww = wv[i]; s1 += ww.x * q.x; s1 += ww.y * q.y; }
   }
@@ -512,8 +520,9 @@ int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off) {
 int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
   if (n && ctx->opt_blas1_vec && al16(x) && al16(y)) {
     const dim3 g(grid_cap((n + 1) / 2, ctx->n_cu));
-    if (b == 0.0) hipLaunchKernelGGL(axpby_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y);
-    else hipLaunchKernelGGL(axpby_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y);
+    const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
+    if (b == 0.0) hipLaunchKernelGGL(axpby_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, nts);
+    else hipLaunchKernelGGL(axpby_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, nts);
   } else
   if (n) hipLaunchKernelGGL(axpby_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y);
   MGS_HIP(ctx, hipGetLastError());
@@ -522,8 +531,9 @@ int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double
 int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z) {
   if (n && ctx->opt_blas1_vec && al16(x) && al16(y) && al16(z)) {
     const dim3 g(grid_cap((n + 1) / 2, ctx->n_cu));
-    if (c == 0.0) hipLaunchKernelGGL(axpbypcz_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
-    else hipLaunchKernelGGL(axpbypcz_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
+    const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
+    if (c == 0.0) hipLaunchKernelGGL(axpbypcz_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z, nts);
+    else hipLaunchKernelGGL(axpbypcz_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z, nts);
   } else
   if (n) hipLaunchKernelGGL(axpbypcz_kernel, dim3(grid_cap(n, ctx->n_cu)), dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z);
   MGS_HIP(ctx, hipGetLastError());
@@ -555,6 +565,57 @@ int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, 
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
+// ---- results of a reduction to the host without a copy engine and without an interrupt
+// The folded values lie in red_dev[DOT_BLOCKS ..].  A one-thread kernel stores them into the context's mapped, coherent host buffer
+// and then a ticket (system-scope release); the host polls the ticket.  Against hipMemcpyAsync + hipStreamSynchronize this removes
+// the blit/SDMA hop and the interrupt wake-up from every inner product of a Krylov loop: four per BiCGSTAB iteration — ≈ 60 of the
+// 135 µs of an iteration on the bundled operators, and on a freshly started box, where the first process' wake-ups take milliseconds,
+// 13 of 33 ms per iteration at 512³ (tools/solve_repeat.py).  Option post_results = 0 restores copy + synchronize; so does any
+// transport that sums over ranks in between (ncomm / all-reduce callback), and a wait that sees no ticket for 2 s.
+__global__ void post_results_kernel(const double *__restrict__ vals, int cnt, double *host_vals, unsigned long long *host_ticket, unsigned long long ticket) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int q = 0; q < cnt; ++q) __hip_atomic_store(host_vals + q, vals[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool posted = ctx->opt_post_results && ctx->red_host_dev && !ctx->ncomm && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess &&
+                      cs == hipStreamCaptureStatusNone;
+  if (posted) {
+    volatile unsigned long long *tk = reinterpret_cast<volatile unsigned long long *>(ctx->red_host + 8);
+    const unsigned long long want = ++ctx->red_ticket;
+    hipLaunchKernelGGL(post_results_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->red_dev + DOT_BLOCKS, cnt, ctx->red_host_dev,
+                       reinterpret_cast<unsigned long long *>(ctx->red_host_dev + 8), want);
+    MGS_HIP(ctx, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (;;) {
+      if (__atomic_load_n(const_cast<unsigned long long *>(tk), __ATOMIC_ACQUIRE) == want) { seen = true; break; }
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > 2.0) break;                                   // never seen: fall back to the stream's own completion below
+      if (waited < 300e-6) { for (int q = 0; q < 8; ++q) __builtin_ia32_pause(); }
+      else { struct timespec ts = {0, 25000}; nanosleep(&ts, nullptr); }     // long kernels ahead of the ticket: stop burning the core
+    }
+    if (seen) { for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q]; }
+    else {
+      MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (__atomic_load_n(const_cast<unsigned long long *>(tk), __ATOMIC_ACQUIRE) != want)
+        return mgs_fail(ctx, MGS_ERR_HIP, "reduction results never reached the host buffer");
+      for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q];
+    }
+  } else {
+    MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q];
+  }
+  if (ctx->allreduce && !ctx->ncomm) {
+    int rc = ctx->allreduce(ctx->allreduce_user, out_host, cnt);
+    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
+  }
+  return MGS_OK;
+}
+
 int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host) {
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
@@ -562,14 +623,7 @@ int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 1));   // sum over the row shards, on this stream
-  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *out_host = ctx->red_host[0];
-  if (ctx->allreduce && !ctx->ncomm) {
-    int rc = ctx->allreduce(ctx->allreduce_user, out_host, 1);
-    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
-  }
-  return MGS_OK;
+  return fetch_results(ctx, 1, out_host);
 }
 
 // middle stage for long partial arrays (one pair per row block of a 512³ operator = 2 × 524 288): workgroup g sums the g-th
@@ -597,14 +651,7 @@ int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part, double *out_host2) {
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, part, ctx->red_dev + DOT_BLOCKS);
   MGS_HIP(ctx, hipGetLastError());
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
-  if (ctx->allreduce && !ctx->ncomm) {
-    int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
-    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
-  }
-  return MGS_OK;
+  return fetch_results(ctx, 2, out_host2);
 }
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2) {
   int nb = (int)((n + TB - 1) / TB);
@@ -613,14 +660,7 @@ int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const doub
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
-  if (ctx->allreduce && !ctx->ncomm) {
-    int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
-    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
-  }
-  return MGS_OK;
+  return fetch_results(ctx, 2, out_host2);
 }
 int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2) {
   int nb = (int)((n + TB - 1) / TB);
@@ -630,20 +670,14 @@ int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, 
     nb = (int)(((n + 1) / 2 + TB - 1) / TB);
     if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
     if (nb < 1) nb = 1;
-    if (w) hipLaunchKernelGGL(update_dot2_partial_vec_kernel<true>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
-    else hipLaunchKernelGGL(update_dot2_partial_vec_kernel<false>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
+    const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
+    if (w) hipLaunchKernelGGL(update_dot2_partial_vec_kernel<true>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev, nts);
+    else hipLaunchKernelGGL(update_dot2_partial_vec_kernel<false>, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev, nts);
   } else
   hipLaunchKernelGGL(update_dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
   hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  out_host2[0] = ctx->red_host[0]; out_host2[1] = ctx->red_host[1];
-  if (ctx->allreduce && !ctx->ncomm) {
-    int rc = ctx->allreduce(ctx->allreduce_user, out_host2, 2);
-    if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed (%d)", rc);
-  }
-  return MGS_OK;
+  return fetch_results(ctx, 2, out_host2);
 }
 int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev) {
   int nb = (int)((n + TB - 1) / TB);

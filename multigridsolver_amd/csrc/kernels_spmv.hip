@@ -37,6 +37,15 @@ __device__ __forceinline__ T ld_stream(const T *p) {
   return *p;
 }
 
+// Streaming store of one output element per lane.  The builtin's hint does not survive here: both arms of `if (nt) nontemporal
+// store else plain store` write the same value to the same address, the optimiser merges them into ONE plain store and the
+// kernel never contained an `nt` store (seen in the ISA; the round-1/2 "nt_store is neutral" A/B compared identical code).  The
+// instruction is spelled out instead.  Nothing in these kernels reads what it stored, so no wait count is owed.
+__device__ __forceinline__ void st_stream(double *p, double v, bool nt) {
+  if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+
 template <int OP>
 __device__ __forceinline__ void epilogue(int row, double s, const double *__restrict__ x,
                                          const double *__restrict__ b, const double *__restrict__ dinv,
@@ -462,7 +471,7 @@ __device__ __forceinline__ void coded_block_body(
     else if (OP == MGS_OP_RESIDUAL) v = bi - s;
     else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
     else v = xin ? (xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
-    if (capi < 0) __builtin_nontemporal_store(v, out + row); else out[row] = v;   // capi < 0: streaming store (A/B option nt_store)
+    st_stream(out + row, v, capi < 0);                                              // capi < 0: streaming store (option nt_store)
     if (OP == MGS_OP_SPMV && dot_part) { bi = v * dot_w1[row]; di = v * v; }       // this row's terms of (y·w1, y·y); bi/di are free in this op
   }
   if (OP == MGS_OP_SPMV && dot_part) {      // launch-uniform: one partial pair per row block, summed in a fixed order
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
     double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
-    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split) {
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts) {
   extern __shared__ double lds_raw[];
   const int g = map_block(bm, blockIdx.x);
   if (g < 0) return;
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     }
     if (row < r1) {
       const double r = bi - s;
-      t_out[row] = bi + r;
+      st_stream(t_out + row, bi + r, nts != 0);
       rbuf[h * RB + tid] = r;
     }
     // members of stray aggregates also store r — the whole wave does when one of its rows must: 64 consecutive doubles are four full
@@ -1281,7 +1290,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                            c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
-                                           ctx->opt_nt_store ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
+                                           (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
                                            O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB)
   // group sweep (views with A->sweep set; plain index codes, no halo): one workgroup per row-block group of the grouped pre pass
   BlockMap gbm; dim3 ggrid(1);
@@ -1289,7 +1298,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
   if (sweep) ggrid = plan_group_map(A, A->sweep, gbm);
 #define CG_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_group_kernel<O, UU, false, false>), ggrid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                       c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
-                                      ctx->opt_nt_store ? -capi : capi, gbm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
+                                      (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, gbm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
                                       nullptr, nullptr, (A->rows + RB - 1) / RB, A->sweep->gdesc)
 #define CH_(O, UU) do { if (sweep && O == FUSE_POST_MAPPED) CG_(FUSE_POST_MAPPED, UU); \
                         else if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
@@ -1480,7 +1489,7 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
                                       G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
 #define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
-                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
+                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0)
 #define GU_(UU) do { if (pairs) { if (hv) G2_(UU, true); else G2_(UU, false); } else { if (hv) G_(UU, true); else G_(UU, false); } } while (0)
   if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
 #undef GU_

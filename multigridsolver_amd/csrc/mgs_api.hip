@@ -83,9 +83,11 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   c->red_cap = 4096 + 64;    // DOT_BLOCKS partials + the folded results (kernels_aux.hip)
-  if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16) != hipSuccess) {
+  if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
   }
+  for (int q = 0; q < 16; ++q) c->red_host[q] = 0.0;
+  if (hipHostGetDevicePointer((void **)&c->red_host_dev, c->red_host, 0) != hipSuccess) { c->red_host_dev = nullptr; (void)hipGetLastError(); }
   // MGS_OPTIONS="key=value,key=value": initial option values of every context (A/B runs of whole test suites)
   if (const char *env = getenv("MGS_OPTIONS")) {
     std::string all(env);
@@ -146,6 +148,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "native_graph") ctx->opt_native_graph = value;
   else if (k == "native_overlap") ctx->opt_native_overlap = value;
   else if (k == "blas1_vec") ctx->opt_blas1_vec = value;
+  else if (k == "post_results") ctx->opt_post_results = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;

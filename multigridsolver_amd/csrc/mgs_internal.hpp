@@ -20,7 +20,9 @@ struct mgs_ctx {
   // scratch for reductions (device partials + pinned host landing zone)
   double *dot_part = nullptr; int64_t dot_part_cap = 0;   // per-row-block partials of the dots fused into the SpMV epilogue
   double *red_dev = nullptr;
-  double *red_host = nullptr;
+  double *red_host = nullptr;       // 16 doubles, mapped + coherent: [0..8) values, [8] the ticket of the posted-result path
+  double *red_host_dev = nullptr;   // the same buffer as the device sees it (NULL: not mappable, copy + synchronize)
+  unsigned long long red_ticket = 0;
   int red_cap = 0;
   int n_cu = 256;
   // options
@@ -32,7 +34,7 @@ struct mgs_ctx {
   int opt_graph = 1;
   int opt_valcode = 0;   // pattern tuples include the VALUES (rows with equal index shape and equal values share a tuple): coded blocks stream no
                          // matrix entry at all.  Pays only where coefficients repeat (constant-coefficient / piecewise-constant operators): opt-in.
-  int opt_nt_store = 0;  // streaming (non-temporal) stores of the kernel outputs (A/B)
+  int opt_nt_store = 1000000;  // streaming (`nt`) stores of the row-block kernels' outputs on operators with at least this many rows (0: never): SpMV −3.4 %, cycle −1.3 % at 512³
   int opt_split_min_rows = 400000;   // row shards: levels with fewer owned rows exchange first and launch once (no interior/boundary split)
   int opt_rowcode = 1;   // pattern-coded index (8 B per entry streamed instead of 12 where rows repeat their shape)
   int opt_blkptr = 1;    // row-block bounds from the compact blkptr array (0: from rowptr)
@@ -52,6 +54,7 @@ struct mgs_ctx {
   int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/ab_group2.py): 4-block groups 6.21 ms per cycle,
                                // pairs 6.34 ms, separate kernels 6.64 ms
   int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
+  int opt_post_results = 1;   // inner products reach the host through a mapped buffer + ticket the host polls (no copy engine, no interrupt)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:

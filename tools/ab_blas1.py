@@ -21,11 +21,12 @@ def timed(f, reps=20):
 
 
 for rnd in range(2):
-    for opt in (1, 0):
-        ctx.set_option("blas1_vec", opt)
+    for opt, nt in ((1, 1000000), (1, 0), (0, 0)):
+        ctx.set_option("blas1_vec", opt); ctx.set_option("nt_store", nt)
         t1 = timed(lambda: y.axpby(0.5, x, 0.25))
         t2 = timed(lambda: z.axpbypcz(0.5, x, 0.25, y, 0.125))
-        print(f"blas1_vec={opt}: axpby {t1:.3f} ms = {24 * n / t1 / 1e9:.2f} TB/s; axpbypcz {t2:.3f} ms = {32 * n / t2 / 1e9:.2f} TB/s", flush=True)
+        print(f"blas1_vec={opt} nt_store={nt}: axpby {t1:.3f} ms = {24 * n / t1 / 1e9:.2f} TB/s; axpbypcz {t2:.3f} ms = {32 * n / t2 / 1e9:.2f} TB/s", flush=True)
+ctx.set_option("nt_store", 1000000)
 A = ctx.poisson3d(N)
 # fixed number of unpreconditioned iterations: 2 SpMV (+ dots) and the four update kernels each, nothing else
 for rnd in range(2):
