@@ -178,7 +178,7 @@ template <int OP, bool NT, int LANES, int U>
 __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, const double *__restrict__ b, const double *__restrict__ dinv, double omega,
-    double *__restrict__ out, int cap, BlockMap bm, int seq_overflow, const int *__restrict__ blkptr) {
+    double *__restrict__ out, int cap, BlockMap bm, int seq_overflow, const int *__restrict__ blkptr, int nts) {
   extern __shared__ double lds_raw[];
   const int vb = map_block(bm, blockIdx.x);
   if (vb < 0) return;
@@ -229,9 +229,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 #pragma unroll
         for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
       }
-      if (OP == MGS_OP_SPMV) out[row] = s;
-      else if (OP == MGS_OP_RESIDUAL) out[row] = bi - s;
-      else out[row] = xi + (omega * di) * (bi - s);
+      st_stream(out + row, OP == MGS_OP_SPMV ? s : (OP == MGS_OP_RESIDUAL ? bi - s : xi + (omega * di) * (bi - s)), nts != 0);
     }
   } else if (seq_overflow) {
     // heavier-than-budget block of short rows: lane t walks row t straight from global memory, same
@@ -1116,9 +1114,9 @@ int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const 
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define L_(LN)                                                                                                 \
   do {                                                                                                         \
-    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
-    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
-    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr); \
+    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
+    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
+    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
   } while (0)
   switch (lanes) {
     case 4: L_(4); break;
@@ -1511,11 +1509,7 @@ int mgs_spmv_dots(const mgs_csr *A, const double *x, double *y, const double *w1
     MGS_TRY(mgs_launch_csr_op(A, MGS_OP_SPMV, x, nullptr, nullptr, 0.0, y));
     return k_dot2(ctx, A->rows, y, w1, y, y, out_host2);
   }
-  if (ctx->dot_part_cap < 2 * (int64_t)nb) {
-    if (ctx->dot_part) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dot_part); ctx->dot_part = nullptr; }
-    MGS_TRY(mgs_dev_alloc(ctx, &ctx->dot_part, (size_t)2 * nb));
-    ctx->dot_part_cap = 2 * (int64_t)nb;
-  }
+  MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nb));
   mgs_csr V = *A; V.owns = false; V.dot_w1 = w1; V.dot_part = ctx->dot_part;     // every row block of the launch writes its pair
   MGS_TRY(mgs_launch_csr_op(&V, MGS_OP_SPMV, x, nullptr, nullptr, 0.0, y));
   return k_dot2_finish(ctx, nb, ctx->dot_part, out_host2);

@@ -299,6 +299,7 @@ int k_dense_gemv(mgs_ctx *ctx, int n, const double *M, const double *b, double *
 int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev);
 int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2);
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2);
+int mgs_ensure_dot_part(mgs_ctx *ctx, int64_t doubles);   // per-workgroup partial pairs of one-shot reduction launches
 int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part /*[2][nb]*/, double *out_host2);   // second stage + rank reduction + host copy
 // y = A·x with (y·w1, y·y) from the same pass where the pattern-coded kernel serves A (else SpMV + k_dot2): BiCGSTAB's
 // v = A·p̂ with r̃·v (bicg.cpp:107-108) and t = A·ŝ with (t·s, t·t) (bicg.cpp:117-118)
