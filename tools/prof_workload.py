@@ -19,8 +19,10 @@ A.optimize()                 # pattern code of the column array (what hierarchie
 ctx.set_option("graph", 0)   # eager launches so every kernel shows up as its own dispatch
 # calibration: axpbypcz_kernel z = 2x + 3b + 0.5z reads 24n bytes and writes 8n bytes with 8-byte lanes
 # (a kernel the V-cycle itself never launches, so every dispatch of it is a calibration launch)
+ctx.set_option("blas1_vec", 0)       # the 8-byte-lane form the earlier summaries were calibrated on (the 16-byte form is what solves launch)
 for _ in range(3):
     mg.lib().mgs_axpbypcz(2.0, x.h, 3.0, b.h, 0.5, y.h)
+ctx.set_option("blas1_vec", 1)
 for _ in range(reps):
     A.spmv(x, y)
 for _ in range(reps):
