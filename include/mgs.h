@@ -54,6 +54,9 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out);
 int mgs_ctx_destroy(mgs_ctx *ctx);
 const char *mgs_last_error(const mgs_ctx *ctx); /* ctx may be NULL: last global error */
 int mgs_sync(mgs_ctx *ctx);                      /* hipStreamSynchronize              */
+/* Releases the memory the context keeps between calls (the Krylov solvers' work vectors: eight vectors of the operator's size
+ * after a BiCGSTABiml solve, bicg.cpp:75 declares them per call; the scratch of the fused inner products). */
+int mgs_ctx_trim(mgs_ctx *ctx);
 void *mgs_ctx_stream(mgs_ctx *ctx);              /* the hipStream_t in use            */
 const char *mgs_version(void);
 

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "mgs_ctx_destroy": (C.c_int, [C.c_void_p]),
     "mgs_last_error": (C.c_char_p, [C.c_void_p]),
     "mgs_sync": (C.c_int, [C.c_void_p]),
+    "mgs_ctx_trim": (C.c_int, [C.c_void_p]),
     "mgs_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "mgs_version": (C.c_char_p, []),
     "mgs_mtx_read": (C.c_int, [C.c_char_p, c_int_p, c_int_p, c_int_p, C.POINTER(c_int_p), C.POINTER(c_int_p), C.POINTER(c_dbl_p)]),

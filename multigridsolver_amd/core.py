@@ -33,6 +33,10 @@ class Context:
     def sync(self):
         check(lib().mgs_sync(self.h), self.h)
 
+    def trim(self):
+        """release the work vectors and scratch the context keeps between solves (mgs_ctx_trim)"""
+        check(lib().mgs_ctx_trim(self.h), self.h)
+
     @property
     def stream(self):
         return lib().mgs_ctx_stream(self.h)

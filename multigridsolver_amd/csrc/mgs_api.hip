@@ -108,6 +108,8 @@ int mgs_ctx_destroy(mgs_ctx *c) {
   if (!c) return MGS_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  for (mgs_vec *v : c->ws_free) mgs_vec_destroy(v);
+  c->ws_free.clear();
   if (c->red_dev) hipFree(c->red_dev);
   if (c->dot_part) hipFree(c->dot_part);
   if (c->red_host) hipHostFree(c->red_host);
@@ -119,6 +121,15 @@ int mgs_ctx_destroy(mgs_ctx *c) {
 const char *mgs_last_error(const mgs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_mgs_last_error.c_str(); }
 int mgs_sync(mgs_ctx *ctx) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MGS_OK; }
 void *mgs_ctx_stream(mgs_ctx *ctx) { return (void *)ctx->stream; }
+// Releases what the context keeps between calls: the Krylov solvers' work vectors (8 vectors of the operator's size after a
+// BiCGSTAB solve) and the partial-sum scratch of the fused inner products.
+int mgs_ctx_trim(mgs_ctx *ctx) {
+  MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (mgs_vec *v : ctx->ws_free) mgs_vec_destroy(v);
+  ctx->ws_free.clear();
+  if (ctx->dot_part) { hipFree(ctx->dot_part); ctx->dot_part = nullptr; ctx->dot_part_cap = 0; }
+  return MGS_OK;
+}
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   std::string k(key ? key : "");
   if (k == "xcd_remap") ctx->opt_xcd_remap = value;
@@ -1094,6 +1105,26 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   return MGS_OK;
 }
 
+// Work vectors of the solvers come from the context and go back to it: a solve no longer pays 8 × (hipMalloc + memset + hipFree,
+// the last one a device synchronisation) per call, and — what matters more — a repeated solve finds its vectors at the SAME
+// addresses, so the captured cycles keyed by (rhs, out) are replayed instead of captured again.  The solvers write every vector
+// before they read it; only the halo slots behind the owned entries of a row shard are cleared on reuse.
+static int ws_get(mgs_ctx *ctx, int64_t n, int64_t owned, mgs_vec **out) {
+  for (size_t i = ctx->ws_free.size(); i-- > 0;) {
+    if (ctx->ws_free[i]->n == n) {
+      *out = ctx->ws_free[i]; ctx->ws_free.erase(ctx->ws_free.begin() + (long)i);
+      if (n > owned) MGS_HIP(ctx, hipMemsetAsync((*out)->d + owned, 0, sizeof(double) * (size_t)(n - owned), ctx->stream));
+      return MGS_OK;
+    }
+  }
+  return mgs_vec_create(ctx, n, out);
+}
+static void ws_put(mgs_ctx *ctx, mgs_vec *v) {
+  if (!v) return;
+  if (ctx->ws_free.size() >= 24) { mgs_vec *old = ctx->ws_free.front(); ctx->ws_free.erase(ctx->ws_free.begin()); mgs_vec_destroy(old); }
+  ctx->ws_free.push_back(v);
+}
+
 // BiCGSTABiml, reference src/common/bicg.cpp:74-136, statement by statement on device vectors.
 int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int *max_iter, double *tol, int *status) {
   mgs_ctx *ctx = A->ctx;
@@ -1102,13 +1133,13 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
   const int n = A->rows, next = A->cols > n ? A->cols : n;
   MGS_CHECK(ctx, x->n >= n && b->n >= n, MGS_ERR_INVALID, "mgs_bicgstab: vectors shorter than %d", n);
   mgs_vec *p = 0, *phat = 0, *s = 0, *shat = 0, *t = 0, *v = 0, *r = 0, *rt = 0, *xe = 0;
-  struct Guard { std::vector<mgs_vec **> vs; ~Guard() { for (auto q : vs) mgs_vec_destroy(*q); } } guard;
-  for (mgs_vec **q : {&p, &phat, &s, &shat, &t, &v, &r, &rt}) { MGS_TRY(mgs_vec_create(ctx, q == &phat || q == &shat ? next : n, q)); guard.vs.push_back(q); }
+  struct Guard { mgs_ctx *c; std::vector<mgs_vec **> vs; ~Guard() { hipStreamSynchronize(c->stream); for (auto q : vs) ws_put(c, *q); } } guard{ctx, {}};
+  for (mgs_vec **q : {&p, &phat, &s, &shat, &t, &v, &r, &rt}) { MGS_TRY(ws_get(ctx, q == &phat || q == &shat ? next : n, n, q)); guard.vs.push_back(q); }
   // views of the owned part so BLAS-1 sizes agree
   auto view = [&](mgs_vec *full, mgs_vec &out) { out.ctx = ctx; out.n = n; out.d = full->d; out.owns = false; };
   mgs_vec xv, bv, phv, shv; view(x, xv); view(const_cast<mgs_vec *>(b), bv); view(phat, phv); view(shat, shv);
   const mgs_vec *xin = x;
-  if (x->n < next) { MGS_TRY(mgs_vec_create(ctx, next, &xe)); guard.vs.push_back(&xe); MGS_TRY(mgs_vec_copy(&xv, xe)); xin = xe; }
+  if (x->n < next) { MGS_TRY(ws_get(ctx, next, n, &xe)); guard.vs.push_back(&xe); MGS_TRY(mgs_vec_copy(&xv, xe)); xin = xe; }
   auto halo0 = [&](mgs_vec *w) -> int {
     if (!h) return 0;
     if (h->lev[0].nx) return native_exchange(h, 0, 2, w->d, nullptr, w->d + A->rows);
@@ -1167,8 +1198,8 @@ int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int re
   MGS_CHECK(ctx, A->rows == A->cols && x->n >= A->rows && b->n >= A->rows, MGS_ERR_INVALID, "mgs_fgcr: square unsharded operator required");
   MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(A)));
   const int n = A->rows;
-  struct Guard { std::vector<mgs_vec *> vs; ~Guard() { for (auto q : vs) mgs_vec_destroy(q); } } guard;
-  auto mk = [&](mgs_vec **q) -> int { int rc = mgs_vec_create(ctx, n, q); if (rc == MGS_OK) guard.vs.push_back(*q); return rc; };
+  struct Guard { mgs_ctx *c; std::vector<mgs_vec *> vs; ~Guard() { hipStreamSynchronize(c->stream); for (auto q : vs) ws_put(c, q); } } guard{ctx, {}};
+  auto mk = [&](mgs_vec **q) -> int { int rc = ws_get(ctx, n, n, q); if (rc == MGS_OK) guard.vs.push_back(*q); return rc; };
   mgs_vec *r = nullptr; MGS_TRY(mk(&r));
   std::vector<mgs_vec *> C((size_t)restart, nullptr), V((size_t)restart, nullptr);
   std::vector<double> rho((size_t)restart, 0.0);

@@ -20,6 +20,7 @@ struct mgs_ctx {
   // scratch for reductions (device partials + pinned host landing zone)
   double *dot_part = nullptr; int64_t dot_part_cap = 0;   // per-row-block partials of the dots fused into the SpMV epilogue
   double *red_dev = nullptr;
+  std::vector<struct mgs_vec *> ws_free;   // work vectors of the Krylov solvers, kept between solves (mgs_ctx_trim releases them)
   double *red_host = nullptr;       // 16 doubles, mapped + coherent: [0..8) values, [8] the ticket of the posted-result path
   double *red_host_dev = nullptr;   // the same buffer as the device sees it (NULL: not mappable, copy + synchronize)
   unsigned long long red_ticket = 0;

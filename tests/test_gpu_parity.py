@@ -401,6 +401,38 @@ def test_blas1_update_kernels_16_byte_forms(ctx, mg, orc):
         ctx.set_option("blas1_vec", 1)
 
 
+def test_solver_workspace_reuse_and_trim(ctx, mg, orc):
+    """the Krylov solvers take their work vectors from the context and hand them back (the reference declares them per call,
+    bicg.cpp:75): a repeated solve gives the same bits whether its vectors are new, reused (stale contents of the previous solve,
+    of ANOTHER operator's solve in between) or re-created after mgs_ctx_trim"""
+    A_o = orc.poisson2d(48)
+    P_o = A_o.agmg(10.0, 2, 8.0)
+    A = dev(ctx, A_o)
+    h = mg.Hierarchy(A, omega=0.6, nu1=1, nu2=1).push_P(dev(ctx, P_o)).finalize()
+    n = A_o.shape[0]
+    b = ctx.vec(orc.rand_rhs(n))
+    B_o = orc.poisson2d(31)
+    B = dev(ctx, B_o); bb = ctx.vec(orc.rand_rhs(B_o.shape[0]))
+    ctx.trim()
+    runs = []
+    for k in range(5):
+        xs = ctx.vec(n)
+        st, it, tol = mg.bicgstab(A, xs, b, h, 200, 1e-10)
+        assert st == 0
+        xf = ctx.vec(n)
+        stf, itf, tolf = mg.fgcr(A, xf, b, h, 5, 200, 1e-10)
+        assert stf == 0
+        runs.append((it, tol, xs.numpy(), itf, tolf, xf.numpy()))
+        if k == 1: ctx.trim()
+        if k == 2:                                   # same-size pool entries are taken by a different operator's solve in between
+            xo = ctx.vec(B_o.shape[0]); mg.bicgstab(B, xo, bb, None, 50, 1e-8)
+            xo2 = ctx.vec(n); mg.bicgstab(A, xo2, ctx.vec(orc.rand_rhs(n)[::-1].copy()), None, 30, 1e-30)
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1] and np.array_equal(r[2], runs[0][2])
+        assert r[3] == runs[0][3] and r[4] == runs[0][4] and np.array_equal(r[5], runs[0][5])
+    assert rel(A_o.spmv(runs[0][2]), orc.rand_rhs(n)) <= 1e-9 and rel(A_o.spmv(runs[0][5]), orc.rand_rhs(n)) <= 1e-9
+
+
 def test_device_agmg_hierarchy(ctx, mg, orc, inputs, golden):
     """config 3: hierarchy built on device.  The reference judges aggregate quality by BiCGSTAB
     iteration count (results.txt:48-51); the device matching is deterministic."""
