@@ -468,12 +468,12 @@ __global__ void poisson2d_kernel(int n, int *__restrict__ rowptr, int *__restric
 // 512³ (tools/blas1_grid.py): axpby 0.695 ms with the capped persistent grid (n_cu × 8 workgroups, grid-stride, unroll 4), 0.541 ms
 // one-shot (5.96 TB/s); 2 / 4 / 8 pairs per lane: 0.568 / 0.623 / 0.671 ms — on this part a stream wants many short-lived
 // workgroups, not a few resident ones (the row-block kernels are one-shot already; tools/microbench/rw_mix.hip shows the same).
-// MGS_BLAS1_ITERS=k: k pairs per lane (0: the capped grid), for that A/B.
-static inline int grid_vec(int64_t n2, int ncu) {
-  static const int iters = getenv("MGS_BLAS1_ITERS") ? atoi(getenv("MGS_BLAS1_ITERS")) : 1;
+// Option blas1_pairs = k: k pairs per lane (0: the capped grid), for that A/B.
+static inline int grid_vec(int64_t n2, const mgs_ctx *ctx) {
+  const int iters = ctx->opt_blas1_pairs;
   int64_t g = (n2 + TB - 1) / TB;
   if (iters > 0) { g = (g + iters - 1) / iters; return (int)(g < 1 ? 1 : g); }
-  const int64_t cap = (int64_t)ncu * 8;
+  const int64_t cap = (int64_t)ctx->n_cu * 8;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 // per-workgroup partial pairs of a one-shot reduction launch ([2][nb] doubles; grown outside any capture)
@@ -539,7 +539,7 @@ int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off) {
 }
 int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double *y) {
   if (n && ctx->opt_blas1_vec && al16(x) && al16(y)) {
-    const dim3 g(grid_vec((n + 1) / 2, ctx->n_cu));
+    const dim3 g(grid_vec((n + 1) / 2, ctx));
     const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
     if (b == 0.0) hipLaunchKernelGGL(axpby_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, nts);
     else hipLaunchKernelGGL(axpby_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, nts);
@@ -550,7 +550,7 @@ int k_axpby(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, double
 }
 int k_axpbypcz(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double c, double *z) {
   if (n && ctx->opt_blas1_vec && al16(x) && al16(y) && al16(z)) {
-    const dim3 g(grid_vec((n + 1) / 2, ctx->n_cu));
+    const dim3 g(grid_vec((n + 1) / 2, ctx));
     const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
     if (c == 0.0) hipLaunchKernelGGL(axpbypcz_vec_kernel<false>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z, nts);
     else hipLaunchKernelGGL(axpbypcz_vec_kernel<true>, g, dim3(TB), 0, ctx->stream, n, a, x, b, y, c, z, nts);
@@ -688,7 +688,7 @@ int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, 
   if (nb < 1) nb = 1;
   if (ctx->opt_blas1_vec && al16(x) && al16(y) && al16(z) && al16(w)) {
     // one-shot workgroups (see grid_vec): one partial pair per workgroup, folded in fixed order by k_dot2_finish
-    nb = grid_vec((n + 1) / 2, ctx->n_cu);
+    nb = grid_vec((n + 1) / 2, ctx);
     const int nts = ctx->opt_nt_store > 0 && n >= ctx->opt_nt_store;
     double *part = ctx->red_dev;
     if (nb > DOT_BLOCKS / 2) { MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nb)); part = ctx->dot_part; }
