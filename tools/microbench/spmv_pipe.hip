@@ -94,6 +94,27 @@ __global__ __launch_bounds__(RB) void spmv_xlds(const double *__restrict__ val, 
   y[r0 + tid] = s;
 }
 
+// W: like A, but every wave stages only the value slice of ITS 64 rows (3.5 KiB, contiguous) and nobody waits for the other waves:
+// no workgroup barrier, only the wave's own LDS ordering
+__global__ __launch_bounds__(RB) void spmv_wave(const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, long n, int N) {
+  __shared__ double vals[SLICE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long N2 = (long)N * N, r0 = (long)blockIdx.x * RB;
+  if (r0 >= n) return;
+  constexpr int WS = 64 * NZ;                       // doubles per wave slice (448), 224 pairs
+  const double *src = val + (r0 + 64 * wave) * NZ;
+  double *dst = vals + wave * WS;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    if (c < WS / 2) *reinterpret_cast<double2_t *>(dst + 2 * c) = *reinterpret_cast<const double2_t *>(src + 2 * c);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  y[r0 + tid] = row_sum(dst, lane, r0 + tid, n, N, N2, x);
+}
+
 template <int G>
 __global__ __launch_bounds__(RB) void spmv_reg(const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, long n, int N) {
   __shared__ double vals[SLICE];
@@ -178,6 +199,9 @@ int main(int argc, char **argv) {
   run("T  block-ELL values, no LDS, 64 thr/WG", spmv_ell<1>, 64, val, x, y, n, N, 64);
   run("T  block-ELL values, no LDS, 512 thr/WG", spmv_ell<8>, 512, val, x, y, n, N, 512);
   run("X  A + x runs staged in LDS (16-B loads)", spmv_xlds, RB, val, x, y, n, N);
+  run("W  wave-private slices, no workgroup barrier", spmv_wave, RB, val, x, y, n, N);
+  run("A  regs->LDS, 1 block/WG (again)", spmv_reg<1>, RB, val, x, y, n, N);
+  run("W  wave-private slices (again)", spmv_wave, RB, val, x, y, n, N);
   run("A without the x gather   (64 B/row moved)", spmv_part<1>, RB, val, x, y, n, N);
   run("A without the y store    (64 B/row moved)", spmv_part<2>, RB, val, x, y, n, N);
   run("A without the val stream (16 B/row moved)", spmv_part<3>, RB, val, x, y, n, N);
