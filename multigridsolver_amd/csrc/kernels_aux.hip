@@ -181,6 +181,12 @@ __global__ void gather_pe_kernel(const double *__restrict__ ec, const int *__res
 // ------------------------------------------------------------------ reductions
 // Two-stage deterministic dot: fixed grid of partials (independent of scheduling), then one
 // block folds them in index order.  reference bicg.cpp:64-72 (dot/norm helpers).
+// where the last stage of a reduction posts its results for the host (see fetch_results): mapped host buffer + ticket; hv = NULL: nowhere
+struct Post { double *hv; unsigned long long *ht; unsigned long long ticket; };
+__device__ __forceinline__ void post_to_host(const Post &pa, const double *vals, int cnt) {
+  for (int q = 0; q < cnt; ++q) __hip_atomic_store(pa.hv + q, vals[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(pa.ht, pa.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr int DOT_BLOCKS = 4096;   // partial slots (a pair kernel uses half of them per sum): 8 workgroups per CU on 256 CUs
 __global__ __launch_bounds__(TB) void dot_partial_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ part) {
   __shared__ double sh[TB / 64];
@@ -193,14 +199,14 @@ __global__ __launch_bounds__(TB) void dot_partial_kernel(int64_t n, const double
   __syncthreads();
   if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < TB / 64; ++w) t += sh[w]; part[blockIdx.x] = t; }
 }
-__global__ __launch_bounds__(TB) void dot_final_kernel(int nb, const double *__restrict__ part, double *__restrict__ out) {
+__global__ __launch_bounds__(TB) void dot_final_kernel(int nb, const double *__restrict__ part, double *__restrict__ out, Post pa) {
   __shared__ double sh[TB];
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += TB) s += part[i];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int w = TB / 2; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
-  if (threadIdx.x == 0) out[0] = sh[0];
+  if (threadIdx.x == 0) { const double r = sh[0]; out[0] = r; if (pa.hv) post_to_host(pa, &r, 1); }
 }
 
 // two inner products in one pass and one host round trip: (x·y, z·w) — BiCGSTAB's (t·s, t·t) and (r·r, r̃·r)
@@ -220,17 +226,19 @@ __global__ __launch_bounds__(TB) void dot2_partial_kernel(int64_t n, const doubl
     part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
   }
 }
-__global__ __launch_bounds__(TB) void dot2_final_kernel(int nb, const double *__restrict__ part, double *__restrict__ out) {
+__global__ __launch_bounds__(TB) void dot2_final_kernel(int nb, const double *__restrict__ part, double *__restrict__ out, Post pa) {
   __shared__ double sh[TB];
+  double res[2] = {0.0, 0.0};
   for (int q = 0; q < 2; ++q) {
     double s = 0.0;
     for (int i = threadIdx.x; i < nb; i += TB) s += part[q * nb + i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = TB / 2; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
-    if (threadIdx.x == 0) out[q] = sh[0];
+    if (threadIdx.x == 0) { res[q] = sh[0]; out[q] = sh[0]; }
     __syncthreads();
   }
+  if (threadIdx.x == 0 && pa.hv) post_to_host(pa, res, 2);
 }
 
 // z = a·x + b·y fused with (z·z, w·z): BiCGSTAB's s = r − αv with ‖s‖² and r = s − ωt with (‖r‖², r̃·r) in one pass each
@@ -586,27 +594,24 @@ int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, 
   return MGS_OK;
 }
 // ---- results of a reduction to the host without a copy engine and without an interrupt
-// The folded values lie in red_dev[DOT_BLOCKS ..].  A one-thread kernel stores them into the context's mapped, coherent host buffer
-// and then a ticket (system-scope release); the host polls the ticket.  Against hipMemcpyAsync + hipStreamSynchronize this removes
+// The last stage of a reduction (one workgroup) stores the folded values into red_dev[DOT_BLOCKS ..] and, for the host, into the
+// context's mapped, coherent host buffer, then a ticket (system-scope release); the host polls the ticket.  Against hipMemcpyAsync + hipStreamSynchronize this removes
 // the blit/SDMA hop and the interrupt wake-up from every inner product of a Krylov loop: four per BiCGSTAB iteration — ≈ 60 of the
 // 135 µs of an iteration on the bundled operators, and on a freshly started box, where the first process' wake-ups take milliseconds,
 // 13 of 33 ms per iteration at 512³ (tools/solve_repeat.py).  Option post_results = 0 restores copy + synchronize; so does any
 // transport that sums over ranks in between (ncomm / all-reduce callback), and a wait that sees no ticket for 2 s.
-__global__ void post_results_kernel(const double *__restrict__ vals, int cnt, double *host_vals, unsigned long long *host_ticket, unsigned long long ticket) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    for (int q = 0; q < cnt; ++q) __hip_atomic_store(host_vals + q, vals[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host) {
+static Post begin_post(mgs_ctx *ctx) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool posted = ctx->opt_post_results && ctx->red_host_dev && !ctx->ncomm && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess &&
                       cs == hipStreamCaptureStatusNone;
-  if (posted) {
+  if (!posted) return Post{nullptr, nullptr, 0ull};
+  return Post{ctx->red_host_dev, reinterpret_cast<unsigned long long *>(ctx->red_host_dev + 8), ++ctx->red_ticket};
+}
+// the reduction's last kernel (launched with `pa`) has been enqueued: wait for its results
+static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host, const Post &pa) {
+  if (pa.hv) {
     volatile unsigned long long *tk = reinterpret_cast<volatile unsigned long long *>(ctx->red_host + 8);
-    const unsigned long long want = ++ctx->red_ticket;
-    hipLaunchKernelGGL(post_results_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->red_dev + DOT_BLOCKS, cnt, ctx->red_host_dev,
-                       reinterpret_cast<unsigned long long *>(ctx->red_host_dev + 8), want);
+    const unsigned long long want = pa.ticket;
     MGS_HIP(ctx, hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();
     bool seen = false;
@@ -617,13 +622,12 @@ static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host) {
       if (waited < 300e-6) { for (int q = 0; q < 8; ++q) __builtin_ia32_pause(); }
       else { struct timespec ts = {0, 25000}; nanosleep(&ts, nullptr); }     // long kernels ahead of the ticket: stop burning the core
     }
-    if (seen) { for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q]; }
-    else {
+    if (!seen) {
       MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (__atomic_load_n(const_cast<unsigned long long *>(tk), __ATOMIC_ACQUIRE) != want)
         return mgs_fail(ctx, MGS_ERR_HIP, "reduction results never reached the host buffer");
-      for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q];
     }
+    for (int q = 0; q < cnt; ++q) out_host[q] = ctx->red_host[q];
   } else {
     MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_dev + DOT_BLOCKS, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
     MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -641,9 +645,10 @@ int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out
   if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
-  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  const Post pa = begin_post(ctx);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS, pa);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 1));   // sum over the row shards, on this stream
-  return fetch_results(ctx, 1, out_host);
+  return fetch_results(ctx, 1, out_host, pa);
 }
 
 // middle stage for long partial arrays (one pair per row block of a 512³ operator = 2 × 524 288): workgroup g sums the g-th
@@ -668,19 +673,21 @@ int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part, double *out_host2) {
     hipLaunchKernelGGL(dot2_mid_kernel, dim3(groups), dim3(TB), 0, ctx->stream, nb, chunk, part, ctx->red_dev);
     part = ctx->red_dev; nb = groups;
   }
-  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, part, ctx->red_dev + DOT_BLOCKS);
+  const Post pa = begin_post(ctx);
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, part, ctx->red_dev + DOT_BLOCKS, pa);
   MGS_HIP(ctx, hipGetLastError());
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  return fetch_results(ctx, 2, out_host2);
+  return fetch_results(ctx, 2, out_host2, pa);
 }
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2) {
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, z, w, ctx->red_dev);
-  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  const Post pa = begin_post(ctx);
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS, pa);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  return fetch_results(ctx, 2, out_host2);
+  return fetch_results(ctx, 2, out_host2, pa);
 }
 int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, const double *y, double *z, const double *w, double *out_host2) {
   int nb = (int)((n + TB - 1) / TB);
@@ -698,16 +705,17 @@ int k_update_dot2(mgs_ctx *ctx, int64_t n, double a, const double *x, double b, 
     return k_dot2_finish(ctx, nb, part, out_host2);
   }
   hipLaunchKernelGGL(update_dot2_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, a, x, b, y, z, w, ctx->red_dev);
-  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS);
+  const Post pa = begin_post(ctx);
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, ctx->red_dev + DOT_BLOCKS, pa);
   if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, 2));
-  return fetch_results(ctx, 2, out_host2);
+  return fetch_results(ctx, 2, out_host2, pa);
 }
 int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_dev) {
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, x, y, ctx->red_dev);
-  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, out_dev);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, out_dev, Post{nullptr, nullptr, 0ull});
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
