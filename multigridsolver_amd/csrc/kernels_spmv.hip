@@ -46,6 +46,20 @@ __device__ __forceinline__ void st_stream(double *p, double v, bool nt) {
   else *p = v;
 }
 
+// Value slice of a row block straight from global memory into LDS (no VGPR in between, so nothing for the register allocator to
+// keep alive or spill): piece p = 64 pairs = 1 KiB, wave w takes pieces w, w + 4, w + 8, w + 12; lane l of a piece moves pair 64p + l.
+// Covers up to 1024 pairs (2048 doubles); the caller checks that.  The workgroup barrier that follows waits for the transfers.
+__device__ __forceinline__ void stage_pairs_dma(const double *__restrict__ src, double *lds, int npairs, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = wave + 4 * k;
+    if (p * 64 + lane < npairs)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (p * 64 + lane)),
+                                       (__attribute__((address_space(3))) void *)(lds + 128 * p), 16, 0, 0);
+  }
+}
+
 template <int OP>
 __device__ __forceinline__ void epilogue(int row, double s, const double *__restrict__ x,
                                          const double *__restrict__ b, const double *__restrict__ dinv,
@@ -368,7 +382,7 @@ __device__ __forceinline__ void coded_block_body(
     const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab,
     const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/,
     const double *__restrict__ dot_w1, double *__restrict__ dot_part /*SpMV: (y·w1, y·y) partials [2][nblocks] of this launch (NULL: none)*/,
-    int dot_nb) {
+    int dot_nb, int flags /*kernel-uniform; bit 0: no row is longer than U → the gather step runs once, without a loop; bit 1: loop-free staging (option stage_unroll)*/) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int r0 = blk * RB;
@@ -393,21 +407,46 @@ __device__ __forceinline__ void coded_block_body(
     if (OP != MGS_OP_SPMV) bi = b[row];
     if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
     if (POST) {                                                     // xin = NULL: b holds t = b + r
-      if (dmode) dp = dpos[row];
-      if (!dmode || dp == 255) di = dinv[row];
-      xi = xin ? di * xin[row] : 0.0; base = agg[row]; pei = base >= 0 ? x[base] : 0.0;
+      // Every load of this prologue is independent of the others and none is waited for before the value slice below is in flight:
+      // the ISA of the first form (dpos → branch → dinv → wait; agg → wait → e_c[agg]) held four serialized memory latencies per
+      // workgroup in front of the staging loop, which is why the post pass ran slower per byte than the other ops.  The loads that
+      // depend on agg (e_c of the own aggregate) and on the diagonal's position are issued behind the barrier with the gathers.
+      base = agg[row];
+      if (dmode) dp = dpos[row]; else di = dinv[row];               // kernel-uniform branch
+      if (xin) xi = xin[row];                                       // scaled by di in the epilogue
     }
   }
+  auto late_loads = [&]() {      // POST: what depends on the prologue's loads
+    if (POST && row < r1) {
+      pei = base >= 0 ? x[base] : 0.0;
+      if (dmode && dp == 255) di = dinv[row];                       // diagonal not found in the row: the wd vector after all
+    }
+  };
   double s = 0.0;
   if (staged) {
     const int nch = (nent + 1) >> 1;
     if (coded) {
       if (VAL) { for (int c = tid; c < tlen; c += RB) vals[c] = vtab[t0 + c]; }     // value tuples instead of the value slice (tlen <= capv)
-      else {
+      else if (nch <= 4 * RB && (flags & 2)) {
+        // No loop in front of the barrier: four predicated 16-byte loads per lane, all in flight together with the prologue's per-row
+        // loads.  A loop here makes the compiler drain every outstanding load at its header (s_waitcnt vmcnt(0) in the ISA: wait counts
+        // across a back edge are not tracked), i.e. a workgroup paid one full memory latency for rowptr/b/agg/… and a second one for
+        // its value slice.
+        double2_t rr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int c = tid + k * RB; if (c < nch) rr[k] = *reinterpret_cast<const double2_t *>(val + start + 2 * c); }
+        int tw = 0;
+        if (tid < tlen) tw = tab[t0 + tid];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int c = tid + k * RB; if (c < nch) *reinterpret_cast<double2_t *>(vals + 2 * c) = rr[k]; }
+        if (tid < tlen) ints[tid] = tw;
+        for (int c = tid + RB; c < tlen; c += RB) ints[c] = tab[t0 + c];
+      } else {
 #pragma unroll 4
         for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
+        for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
       }
-      for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
+      if (VAL) for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
     } else {
 #pragma unroll 4
       for (int c = tid; c < nch; c += RB) {
@@ -417,25 +456,34 @@ __device__ __forceinline__ void coded_block_body(
       }
     }
     __syncthreads();
+    late_loads();
     if (row < r1 && ge > ga) {
       const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
       if (coded) {
         const int ps = ints[pid[row]];
         const int last = my_e - my_a - 1;
-        for (int k = my_a, j = 0; k < my_e; k += U, j += U) {
+        auto step = [&](const int k, const int j) {
           int oq[U]; double xv[U], vq[U];
 #pragma unroll
           for (int q = 0; q < U; ++q) oq[q] = ints[ps + min(j + q, last)];   // past the row's end: the row's last index again
 #pragma unroll
           for (int q = 0; q < U; ++q) {
             if (HALO && oq[q] >= CODE_HALO_LO) xv[q] = hv[row + (oq[q] - CODE_HALO)];
-            else xv[q] = (POST && oq[q] == CODE_NEG) ? 0.0 : x[base + oq[q]];
+            else if (POST) {           // unconditional load (a column outside every aggregate reads entry 0 and is zeroed): no branch per gather
+              const bool neg = oq[q] == CODE_NEG;
+              const double g = x[neg ? 0 : base + oq[q]];
+              xv[q] = neg ? 0.0 : g;
+            } else xv[q] = x[base + oq[q]];
           }
 #pragma unroll
           for (int q = 0; q < U; ++q) vq[q] = VAL ? vals[ps + min(j + q, last)] : vals[min(k + q, lim)];
 #pragma unroll
           for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
-        }
+        };
+        // rows that all fit one step (7-point operators with U = 7, A·P with U = 5): straight-line code, so the loads issued behind
+        // the barrier (e_c of the own aggregate) stay in flight beside the gathers instead of being drained at a loop header
+        if ((flags & 3) == 3) step(my_a, 0);
+        else for (int k = my_a, j = 0; k < my_e; k += U, j += U) step(k, j);
         if (POST && dmode && dp != 255) di = omega * (1.0 / (VAL ? vals[ps + (int)dp] : vals[my_a + (int)dp]));
       } else {
         for (int k = my_a; k < my_e; k += U) {
@@ -445,7 +493,8 @@ __device__ __forceinline__ void coded_block_body(
 #pragma unroll
           for (int q = 0; q < U; ++q) {
             if (HALO && cq[q] >= split) xv[q] = hv[cq[q] - split];
-            else xv[q] = (POST && cq[q] < 0) ? 0.0 : x[cq[q]];
+            else if (POST) { const bool neg = cq[q] < 0; const double g = x[neg ? 0 : cq[q]]; xv[q] = neg ? 0.0 : g; }
+            else xv[q] = x[cq[q]];
           }
 #pragma unroll
           for (int q = 0; q < U; ++q) vq[q] = vals[min(k + q, lim)];
@@ -457,6 +506,7 @@ __device__ __forceinline__ void coded_block_body(
     }
   } else if (row < r1) {
     // heavier-than-budget block: lane t walks row t straight from global memory, same ascending order
+    late_loads();
     for (int k = ga; k < ge; ++k) {
       const int c = idx[k];
       s += val[k] * ((HALO && c >= split) ? hv[c - split] : ((POST && c < 0) ? 0.0 : x[c]));
@@ -468,7 +518,7 @@ __device__ __forceinline__ void coded_block_body(
     if (OP == MGS_OP_SPMV) v = s;
     else if (OP == MGS_OP_RESIDUAL) v = bi - s;
     else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
-    else v = xin ? (xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
+    else v = xin ? (di * xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
     st_stream(out + row, v, capi < 0);                                              // capi < 0: streaming store (option nt_store)
     if (OP == MGS_OP_SPMV && dot_part) { bi = v * dot_w1[row]; di = v * v; }       // this row's terms of (y·w1, y·y); bi/di are free in this op
   }
@@ -492,8 +542,8 @@ __device__ __forceinline__ void coded_block_body(
     const double *__restrict__ b, const double *__restrict__ dinv, double omega, const double *__restrict__ xin,                         \
     const int *__restrict__ agg, double *__restrict__ out, int capv, int capi, BlockMap bm, const int *__restrict__ blkptr,               \
     const double *__restrict__ hv, int split, const double *__restrict__ vtab, const unsigned char *__restrict__ dpos,                   \
-    const double *__restrict__ dot_w1, double *__restrict__ dot_part, int dot_nb
-#define CODED_ARGS n, rowptr, idx, val, pid, tptr, tab, x, b, dinv, omega, xin, agg, out, capv, capi, blkptr, hv, split, vtab, dpos, dot_w1, dot_part, dot_nb
+    const double *__restrict__ dot_w1, double *__restrict__ dot_part, int dot_nb, int flags
+#define CODED_ARGS n, rowptr, idx, val, pid, tptr, tab, x, b, dinv, omega, xin, agg, out, capv, capi, blkptr, hv, split, vtab, dpos, dot_w1, dot_part, dot_nb, flags
 
 // (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
 template <int OP, int U, bool HALO, bool VAL>
@@ -821,7 +871,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
     double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
-    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts) {
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts /*bit 0: streaming store of t; bit 1: slice staged by LDS-DMA, no loop*/) {
   extern __shared__ double lds_raw[];
   const int g = map_block(bm, blockIdx.x);
   if (g < 0) return;
@@ -855,7 +905,13 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     double s = 0.0;
     if (staged) {
       const int nch = (nent + 1) >> 1;
-      if (coded) {
+      if (coded && nch <= 4 * RB && (nts & 2)) {          // no loop and no staging registers in front of the barrier (see coded_block_body)
+        stage_pairs_dma(val + start, vals, nch, tid);
+        int tw = 0;
+        if (tid < tlen) tw = tab[t0 + tid];
+        if (tid < tlen) ints[tid] = tw;
+        for (int c = tid + RB; c < tlen; c += RB) ints[c] = tab[t0 + c];
+      } else if (coded) {
 #pragma unroll 4
         for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
         for (int c = tid; c < tlen; c += RB) ints[c] = tab[t0 + c];
@@ -906,7 +962,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     }
     if (row < r1) {
       const double r = bi - s;
-      st_stream(t_out + row, bi + r, nts != 0);
+      st_stream(t_out + row, bi + r, (nts & 1) != 0);
       rbuf[h * RB + tid] = r;
     }
     // members of stray aggregates also store r — the whole wave does when one of its rows must: 64 consecutive doubles are four full
@@ -1289,7 +1345,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 #define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                            c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
                                            (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
-                                           O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB)
+                                           O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0))
   // group sweep (views with A->sweep set; plain index codes, no halo): one workgroup per row-block group of the grouped pre pass
   BlockMap gbm; dim3 ggrid(1);
   const bool sweep = A->sweep && !hv && !c->vtab && op == FUSE_POST_MAPPED;
@@ -1297,7 +1353,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 #define CG_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_group_kernel<O, UU, false, false>), ggrid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                       c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
                                       (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, gbm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
-                                      nullptr, nullptr, (A->rows + RB - 1) / RB, A->sweep->gdesc)
+                                      nullptr, nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0), A->sweep->gdesc)
 #define CH_(O, UU) do { if (sweep && O == FUSE_POST_MAPPED) CG_(FUSE_POST_MAPPED, UU); \
                         else if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
                         else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
@@ -1487,7 +1543,7 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
                                       G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
 #define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
-                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0)
+                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, ((ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0))
 #define GU_(UU) do { if (pairs) { if (hv) G2_(UU, true); else G2_(UU, false); } else { if (hv) G_(UU, true); else G_(UU, false); } } while (0)
   if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
 #undef GU_

@@ -161,6 +161,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "blas1_vec") ctx->opt_blas1_vec = value;
   else if (k == "post_results") ctx->opt_post_results = value;
   else if (k == "blas1_pairs") ctx->opt_blas1_pairs = value;
+  else if (k == "stage_unroll") ctx->opt_stage_unroll = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;
