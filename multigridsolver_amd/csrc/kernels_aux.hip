@@ -120,8 +120,19 @@ __global__ void restrict_agg_kernel(int nc, const int *__restrict__ cptr, const 
                                     const double *__restrict__ r, double *__restrict__ rc) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
+  // aggregates of the pairwise passes hold at most 4 members: the first four member indices, then their four residuals, are loaded
+  // together (predicated, no loop: a loop drains every outstanding load at its header, and member → residual is a dependent pair,
+  // i.e. eight serialized memory latencies per lane in the looped form); the sum keeps the ascending order.  Longer lists continue in a loop.
+  const int k0 = cptr[c], e = cptr[c + 1];
+  int m[4]; double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) m[q] = k0 + q < e ? members[k0 + q] : -1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = m[q] >= 0 ? r[m[q]] : 0.0;
   double s = 0.0;
-  for (int k = cptr[c], e = cptr[c + 1]; k < e; ++k) s += r[members[k]];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (k0 + q < e) s += v[q];
+  for (int k = k0 + 4; k < e; ++k) s += r[members[k]];
   rc[c] = s;
 }
 // e = P e_c / x += P e_c: `P * (...)`, reference bicg.cpp:48; P has ≤1 unit entry per row

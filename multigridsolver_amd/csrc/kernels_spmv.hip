@@ -217,6 +217,8 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
       if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
     }
     const int nch = (hi - start + 1) >> 1;
+    // (a loop-free form of this staging — four predicated int2 + double2 loads per lane — measured 1.5 % SLOWER here, 2.553 against
+    // 2.515 ms: 64 instead of 46 VGPRs; the coded kernels, which stage values only, gain 5–7 % from it)
 #pragma unroll 4
     for (int c = tid; c < nch; c += RB) {
       const int k = start + 2 * c;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(RB) void csr_rowblock_slice_kernel(
 #pragma unroll
         for (int q = 0; q < U; ++q) s += (k + q < my_e) ? vq[q] * xv[q] : 0.0;
       }
-      st_stream(out + row, OP == MGS_OP_SPMV ? s : (OP == MGS_OP_RESIDUAL ? bi - s : xi + (omega * di) * (bi - s)), nts != 0);
+      st_stream(out + row, OP == MGS_OP_SPMV ? s : (OP == MGS_OP_RESIDUAL ? bi - s : xi + (omega * di) * (bi - s)), (nts & 1) != 0);
     }
   } else if (seq_overflow) {
     // heavier-than-budget block of short rows: lane t walks row t straight from global memory, same
@@ -1170,9 +1172,9 @@ int launch_slice(const mgs_csr *A, int lanes, dim3 grid, const double *x, const 
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
 #define L_(LN)                                                                                                 \
   do {                                                                                                         \
-    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
-    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
-    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, (A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0); \
+    if (u == 4) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 4>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, ((A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0) | (A->ctx->opt_stage_unroll ? 2 : 0)); \
+    else if (u == 7) hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 7>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, ((A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0) | (A->ctx->opt_stage_unroll ? 2 : 0)); \
+    else hipLaunchKernelGGL((csr_rowblock_slice_kernel<OP, NT, LN, 8>), grid, dim3(RB), lds, s, A->rows, A->rowptr, A->col, A->val, x, b, dinv, omega, out, cap, bm, A->max_row_len <= 64 ? 1 : 0, A->ctx->opt_blkptr ? A->blkptr : nullptr, ((A->ctx->opt_nt_store > 0 && A->rows >= A->ctx->opt_nt_store) ? 1 : 0) | (A->ctx->opt_stage_unroll ? 2 : 0)); \
   } while (0)
   switch (lanes) {
     case 4: L_(4); break;
