@@ -404,8 +404,10 @@ __device__ __forceinline__ void coded_block_body(
   double bi = 0.0, di = 0.0, xi = 0.0, pei = 0.0;
   const bool dmode = POST && dpos != nullptr && xin == nullptr;    // ωD⁻¹ from the streamed diagonal entry (same bits as wd = ω·(1/a_ii))
   unsigned dp = 255;
+  int mypid = 0;      // the row's pattern id: loaded HERE, with the other per-row loads — behind the barrier it was one more full memory latency in series
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
+    if (coded) mypid = pid[row];
     if (OP != MGS_OP_SPMV) bi = b[row];
     if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
     if (POST) {                                                     // xin = NULL: b holds t = b + r
@@ -462,7 +464,7 @@ __device__ __forceinline__ void coded_block_body(
     if (row < r1 && ge > ga) {
       const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
       if (coded) {
-        const int ps = ints[pid[row]];
+        const int ps = ints[mypid];
         const int last = my_e - my_a - 1;
         auto step = [&](const int k, const int j) {
           int oq[U]; double xv[U], vq[U];
@@ -903,7 +905,8 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     int ga = 0, ge = 0;
     double bi = 0.0;
     unsigned wm = 0u;
-    if (row < r1) { ga = rowptr[row]; ge = rowptr[row + 1]; bi = b[row]; wm = wmask[row >> 5]; }
+    int mypid = 0;                                                        // loaded with the other per-row loads, not behind the barrier
+    if (row < r1) { ga = rowptr[row]; ge = rowptr[row + 1]; bi = b[row]; wm = wmask[row >> 5]; if (coded) mypid = pid[row]; }
     double s = 0.0;
     if (staged) {
       const int nch = (nent + 1) >> 1;
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
       if (row < r1 && ge > ga) {
         const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
         if (coded) {
-          const int ps = ints[pid[row]];
+          const int ps = ints[mypid];
           const int last = my_e - my_a - 1;
           for (int k = my_a, j = 0; k < my_e; k += U, j += U) {
             int oq[U]; double xv[U], vq[U];
