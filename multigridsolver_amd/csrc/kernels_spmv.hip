@@ -408,6 +408,7 @@ __device__ __forceinline__ void coded_block_body(
   if (row < r1) {
     ga = rowptr[row]; ge = rowptr[row + 1];
     if (coded) mypid = pid[row];
+    if (OP == MGS_OP_SPMV && dot_part) bi = dot_w1[row];       // fused dots: w1 of this row (bi is free in this op); loaded here, not behind the store
     if (OP != MGS_OP_SPMV) bi = b[row];
     if (OP == MGS_OP_JACOBI) { di = dinv[row]; xi = x[row]; }
     if (POST) {                                                     // xin = NULL: b holds t = b + r
@@ -524,7 +525,7 @@ __device__ __forceinline__ void coded_block_body(
     else if (OP == MGS_OP_JACOBI) v = xi + (omega * di) * (bi - s);
     else v = xin ? (di * xi + pei) + di * (bi - s) : pei + di * (bi - s);     // t-form: x = Pe + wd∘(t − A·Pe), t = b + r
     st_stream(out + row, v, capi < 0);                                              // capi < 0: streaming store (option nt_store)
-    if (OP == MGS_OP_SPMV && dot_part) { bi = v * dot_w1[row]; di = v * v; }       // this row's terms of (y·w1, y·y); bi/di are free in this op
+    if (OP == MGS_OP_SPMV && dot_part) { bi = v * bi; di = v * v; }                // this row's terms of (y·w1, y·y); bi/di are free in this op
   }
   if (OP == MGS_OP_SPMV && dot_part) {      // launch-uniform: one partial pair per row block, summed in a fixed order
     double p1 = row < r1 ? bi : 0.0, p2 = row < r1 ? di : 0.0;
@@ -965,14 +966,17 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     } else if (row < r1) {
       for (int k = ga; k < ge; ++k) { const int c = idx[k]; s += val[k] * ((HALO && c >= split) ? hv[c - split] : x[c]); }
     }
+    // members of stray aggregates also store r — the whole wave does when one of its rows must: 64 consecutive doubles are four full
+    // cache lines, while lone 8-byte stores each cost a read-modify-write of an ECC word in HBM.  The vote is taken BEFORE the stores:
+    // read after them, the mask (a loaded value) made the compiler wait for vmcnt(0) behind the t store, i.e. for the store itself to
+    // complete, once per row block of the sweep.
+    const bool stray_wave = __any((int)((wm >> (row & 31)) & 1u)) != 0;
     if (row < r1) {
       const double r = bi - s;
       st_stream(t_out + row, bi + r, (nts & 1) != 0);
       rbuf[h * RB + tid] = r;
+      if (stray_wave) r_out[row] = r;
     }
-    // members of stray aggregates also store r — the whole wave does when one of its rows must: 64 consecutive doubles are four full
-    // cache lines, while lone 8-byte stores each cost a read-modify-write of an ECC word in HBM
-    if (__any((int)((wm >> (row & 31)) & 1u)) && row < r1) r_out[row] = bi - s;
   }
   __syncthreads();
 #pragma unroll
