@@ -514,6 +514,7 @@ int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int
   for (int p = 0; p < world; ++p) { T->maxn = std::max(T->maxn, nlocs[p]); }
   for (int p = 0; p < world; ++p) { if (p == rank) T->my_off = (int)gi.size(); for (int j = 0; j < nlocs[p]; ++j) gi.push_back(p * T->maxn + j); }
   T->n_t = (int)gi.size();
+  T->even = T->maxn > 0; for (int p = 0; p < world; ++p) T->even = T->even && nlocs[p] == T->maxn;
   if (!(T->n_t == tail->lev[0].n && T->n_loc == h->lev.back().n))
     return fail(mgs_fail(ctx, MGS_ERR_INVALID, "mgs_hier_set_native_tail: tail has %d rows, shards sum to %d", tail->lev[0].n, T->n_t));
   int rc = mgs_dev_alloc(ctx, &T->send, (size_t)std::max(T->maxn, 1));
@@ -805,11 +806,17 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
   if (l == (int)h->lev.size() - 1) {
     if (h->ntail) {                                     // replicated tail, native: all-gather the rhs, cycle, own slice back
       mgs_native_tail *T = h->ntail;
-      if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(T->send, b, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
-      MGS_TRY(mgs_comm_allgather(T->comm, T->send, T->all, (size_t)std::max(T->maxn, 1)));
-      MGS_TRY(k_gather(ctx, T->all, T->gidx, T->n_t, T->b->d));
-      if (h->capturing) MGS_TRY(cycle_level(T->tail, 0, T->b->d, T->x->d, true));   // part of the outer graph (prepare_fused ran before the capture)
-      else MGS_TRY(mgs_vcycle(T->tail, T->b, T->x, 1));
+      const double *tb = T->b->d;
+      if (T->even) {        // equal shards: gather straight from b; the gathered buffer is already in the tail's row order (two dispatches less per cycle)
+        MGS_TRY(mgs_comm_allgather(T->comm, b, T->all, (size_t)T->maxn));
+        tb = T->all;
+      } else {
+        if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(T->send, b, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
+        MGS_TRY(mgs_comm_allgather(T->comm, T->send, T->all, (size_t)std::max(T->maxn, 1)));
+        MGS_TRY(k_gather(ctx, T->all, T->gidx, T->n_t, T->b->d));
+      }
+      if (h->capturing) MGS_TRY(cycle_level(T->tail, 0, tb, T->x->d, true));   // part of the outer graph (prepare_fused ran before the capture)
+      else { mgs_vec bv; bv.ctx = ctx; bv.n = T->n_t; bv.d = const_cast<double *>(tb); bv.owns = false; MGS_TRY(mgs_vcycle(T->tail, &bv, T->x, 1)); }
       if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(x, T->x->d + T->my_off, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
       return MGS_OK;
     }

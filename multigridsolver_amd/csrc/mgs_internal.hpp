@@ -150,6 +150,7 @@ struct mgs_native_tail {
   mgs_comm *comm = nullptr;
   mgs_hier *tail = nullptr;         // not owned
   int maxn = 0, n_t = 0, my_off = 0, n_loc = 0;
+  bool even = false;                // every rank holds maxn rows: the gathered buffer is the tail's right-hand side as it stands
   double *send = nullptr, *all = nullptr;   // maxn / world·maxn doubles
   int *gidx = nullptr;              // n_t: position of global tail row i in `all`
   mgs_vec *b = nullptr, *x = nullptr;
