@@ -340,7 +340,9 @@ int mgs_hier_group_info(const mgs_hier *h, int level, int64_t out[4]);
 int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements (initial values of every context: environment MGS_OPTIONS="key=value,...").  key: "spmv_variant", "xcd_remap", "nontemporal",
- * "graph", "strip", "fuse", "nt_store" (streaming stores, measured neutral), "valcode" (opt-in: pattern tuples carry the values too, set before
+ * "graph", "strip", "fuse", "nt_store" (smallest operator, in rows, whose row-block kernels store their outputs with the `nt` hint; default 1000000,
+ * 0 = never), "stage_unroll" (row-block kernels stage their value slice without a loop in front of the barrier; default 1), "blas1_vec" / "blas1_pairs" (16-byte update
+ * kernels, pairs per lane: 1 = one-shot workgroups; defaults 1 / 1), "post_results" (inner products reach the host through a mapped buffer and a polled ticket; default 1), "valcode" (opt-in: pattern tuples carry the values too, set before
  * mgs_csr_optimize / the hierarchy is built; pays only where coefficients repeat), "rowcode" (pattern-coded index, default 1), "split_min_rows" (row shards: smallest level that
  * overlaps its halo exchange with interior row blocks, default 400000), "fuse_operands" (setup-time operands of the fused cycle passes,
  * +12 B of HBM per matrix entry; default 1), "merge_ap" (fused post pass on A·P with the entries of one aggregate summed at setup instead of A with
