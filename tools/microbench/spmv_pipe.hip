@@ -94,6 +94,31 @@ __global__ __launch_bounds__(RB) void spmv_xlds(const double *__restrict__ val, 
   y[r0 + tid] = s;
 }
 
+// Z: like A, but the x gathers are issued BEFORE the barrier, beside the loads of the value slice (possible here because the
+// columns follow from the row number; in the product they come from the block's pattern table in LDS): what would ONE memory latency
+// per workgroup instead of two be worth?
+__global__ __launch_bounds__(RB) void spmv_early(const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, long n, int N) {
+  __shared__ double vals[SLICE];
+  const int tid = threadIdx.x;
+  const long N2 = (long)N * N, r0 = (long)blockIdx.x * RB;
+  if (r0 >= n) return;
+  const double *src = val + r0 * NZ;
+  const long row = r0 + tid;
+  const long off[NZ] = {-N2, -N, -1, 0, 1, N, N2};
+  double2_t rr[4]; double xv[NZ];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int c = tid + k * RB; if (c < SLICE / 2) rr[k] = *reinterpret_cast<const double2_t *>(src + 2 * c); }
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) { long c = row + off[q]; c = c < 0 ? 0 : (c >= n ? n - 1 : c); xv[q] = x[c]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int c = tid + k * RB; if (c < SLICE / 2) *reinterpret_cast<double2_t *>(vals + 2 * c) = rr[k]; }
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) s += vals[tid * NZ + q] * xv[q];
+  y[row] = s;
+}
+
 // W: like A, but every wave stages only the value slice of ITS 64 rows (3.5 KiB, contiguous) and nobody waits for the other waves:
 // no workgroup barrier, only the wave's own LDS ordering
 __global__ __launch_bounds__(RB) void spmv_wave(const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, long n, int N) {
@@ -202,6 +227,9 @@ int main(int argc, char **argv) {
   run("W  wave-private slices, no workgroup barrier", spmv_wave, RB, val, x, y, n, N);
   run("A  regs->LDS, 1 block/WG (again)", spmv_reg<1>, RB, val, x, y, n, N);
   run("W  wave-private slices (again)", spmv_wave, RB, val, x, y, n, N);
+  run("Z  gathers issued before the barrier", spmv_early, RB, val, x, y, n, N);
+  run("A  regs->LDS, 1 block/WG (again)", spmv_reg<1>, RB, val, x, y, n, N);
+  run("Z  gathers issued before the barrier (again)", spmv_early, RB, val, x, y, n, N);
   run("A without the x gather   (64 B/row moved)", spmv_part<1>, RB, val, x, y, n, N);
   run("A without the y store    (64 B/row moved)", spmv_part<2>, RB, val, x, y, n, N);
   run("A without the val stream (16 B/row moved)", spmv_part<3>, RB, val, x, y, n, N);
