@@ -175,3 +175,31 @@ def test_loader_rejects_what_the_stream_reader_rejects(tmp_path, monkeypatch, th
     p.write_text("%h\n4 6 0\n")
     rows, cols, rp, ci, v = mg.read_mtx(str(p))
     assert (rows, cols) == (4, 6) and rp.tolist() == [0] * 5 and len(ci) == 0 and len(v) == 0
+
+
+def test_loader_default_threads_on_a_multi_megabyte_file(tmp_path):
+    """a file large enough for the loader to cut it into several pieces by itself (no MGS_IO_THREADS): shuffled entries of a 2-D
+    five-point operator with random values, written with repr() (17 digits) — arrays equal to scipy's assembly; the writer's output
+    read back gives the %g-rounded values and the same pattern"""
+    import multigridsolver_amd as mg
+    import scipy.sparse as sps
+    n = 230
+    I = sps.identity(n); T = sps.diags([-1, -1], [-1, 1], shape=(n, n))
+    A = (sps.kron(I, sps.diags([4], [0], shape=(n, n)) + T) + sps.kron(T, I)).tocoo()
+    rng = np.random.default_rng(5)
+    vals = rng.standard_normal(A.nnz) * 10.0 ** rng.integers(-8, 8, A.nnz)
+    perm = rng.permutation(A.nnz)
+    p = tmp_path / "big.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% shuffled\n")
+        f.write(f"{n * n} {n * n} {A.nnz}\n")
+        f.write("".join(f"{A.row[k] + 1} {A.col[k] + 1} {float(vals[k])!r}\n" for k in perm))
+    assert p.stat().st_size > 4 << 20
+    rows, cols, rp, ci, v = mg.read_mtx(str(p))
+    ref = sps.csr_matrix((vals, (A.row, A.col)), shape=(n * n, n * n)); ref.sort_indices()
+    assert (rows, cols) == ref.shape and np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(v, ref.data)
+    q = tmp_path / "out.mtx"
+    mg.write_mtx(str(q), rows, cols, rp, ci, v)
+    r2 = mg.read_mtx(str(q))
+    assert np.array_equal(r2[2], rp) and np.array_equal(r2[3], ci)
+    assert np.array_equal(r2[4], np.array([float("%g" % x) for x in v]))
