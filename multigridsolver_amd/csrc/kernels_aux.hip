@@ -311,6 +311,35 @@ __global__ __launch_bounds__(TB) void update_dot2_partial_vec_kernel(int64_t n, 
   }
 }
 
+// one or two inner products, one pair of elements per lane, one-shot workgroups (see grid_vec): partial pair per workgroup ([2][gridDim.x];
+// NP = 1 leaves the second sum at zero so that the staged fold of the pairs serves both)
+template <int NP>
+__global__ __launch_bounds__(TB) void dot_block_vec_kernel(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                           const double *__restrict__ z, const double *__restrict__ w, double *__restrict__ part) {
+  __shared__ double sh[2][TB / 64];
+  const int64_t n2 = n >> 1;
+  const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
+  const vd2 *__restrict__ yv = reinterpret_cast<const vd2 *>(y);
+  const vd2 *__restrict__ zv = reinterpret_cast<const vd2 *>(z);
+  const vd2 *__restrict__ wv = reinterpret_cast<const vd2 *>(w);
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * TB;
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+    const vd2 p = xv[i], q = yv[i];
+    s0 += p.x * q.x; s0 += p.y * q.y;
+    if (NP == 2) { const vd2 a = zv[i], b = wv[i]; s1 += a.x * b.x; s1 += a.y * b.y; }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { s0 += x[n - 1] * y[n - 1]; if (NP == 2) s1 += z[n - 1] * w[n - 1]; }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 // ------------------------------------------------------------------ K-cycle helpers (device-resident scalars)
 // Two GCR steps on the coarse problem (Notay, SISC 34 (2012), K-cycle for nonsymmetric problems): scal =
 // {ρ1 = v1·v1, α1 = v1·r, γ = v2·v1, β = v2·v2, α2 = v2·r'}; no host round trip, graph-capturable.
@@ -652,6 +681,17 @@ static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host, const Post &pa
 }
 
 int k_dot(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double *out_host) {
+  if (ctx->opt_blas1_vec && n >= 2 && al16(x) && al16(y)) {       // one-shot workgroups, staged fold (as the fused update kernels)
+    const int nbv = grid_vec(n / 2, ctx);
+    double *part = ctx->red_dev;
+    if (nbv > DOT_BLOCKS / 2) { MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nbv)); part = ctx->dot_part; }
+    hipLaunchKernelGGL(dot_block_vec_kernel<1>, dim3(nbv), dim3(TB), 0, ctx->stream, n, x, y, x, y, part);
+    MGS_HIP(ctx, hipGetLastError());
+    double two[2] = {0.0, 0.0};
+    MGS_TRY(k_dot2_finish(ctx, nbv, part, two));
+    *out_host = two[0];
+    return MGS_OK;
+  }
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS) nb = DOT_BLOCKS;
   if (nb < 1) nb = 1;
@@ -691,6 +731,14 @@ int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part, double *out_host2) {
   return fetch_results(ctx, 2, out_host2, pa);
 }
 int k_dot2(mgs_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, const double *w, double *out_host2) {
+  if (ctx->opt_blas1_vec && n >= 2 && al16(x) && al16(y) && al16(z) && al16(w)) {
+    const int nbv = grid_vec(n / 2, ctx);
+    double *part = ctx->red_dev;
+    if (nbv > DOT_BLOCKS / 2) { MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nbv)); part = ctx->dot_part; }
+    hipLaunchKernelGGL(dot_block_vec_kernel<2>, dim3(nbv), dim3(TB), 0, ctx->stream, n, x, y, z, w, part);
+    MGS_HIP(ctx, hipGetLastError());
+    return k_dot2_finish(ctx, nbv, part, out_host2);
+  }
   int nb = (int)((n + TB - 1) / TB);
   if (nb > DOT_BLOCKS / 2) nb = DOT_BLOCKS / 2;
   if (nb < 1) nb = 1;
