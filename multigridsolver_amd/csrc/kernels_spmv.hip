@@ -370,7 +370,8 @@ constexpr int CODE_NEG = (int)0x80000000;   // table word of a negative index (c
 // slot − row (constant along a plane boundary, where index − base is not): word = CODE_HALO + (slot − row).
 constexpr int CODE_HALO = 0x60000000, CODE_HALO_LO = 0x50000000, CODE_OFF_MAX = 0x40000000;
 
-// (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
+// (round 1: the post pass took 68 VGPRs unbounded = 7 waves per SIMD, bounded to 8 waves it measured 2 % faster, the other ops 0.5–0.8 % slower;
+// since its prologue was rewritten it needs 52–56, the other ops 58–64, and the bound no longer binds)
 // VAL: the tuples carry the values as well (`vtab`, option valcode): a coded block then streams no matrix entry at all.
 // one 256-row block of the pattern-coded kernel (the two __global__ wrappers below call it once per workgroup, or once per row block
 // of a group of blocks)
@@ -550,7 +551,8 @@ __device__ __forceinline__ void coded_block_body(
     const double *__restrict__ dot_w1, double *__restrict__ dot_part, int dot_nb, int flags
 #define CODED_ARGS n, rowptr, idx, val, pid, tptr, tab, x, b, dinv, omega, xin, agg, out, capv, capi, blkptr, hv, split, vtab, dpos, dot_w1, dot_part, dot_nb, flags
 
-// (the post pass would take 68 VGPRs = 7 waves per SIMD; bounded to 8 waves it measures 2 % faster, the other ops 0.5–0.8 % slower)
+// (round 1: the post pass took 68 VGPRs unbounded = 7 waves per SIMD, bounded to 8 waves it measured 2 % faster, the other ops 0.5–0.8 % slower;
+// since its prologue was rewritten it needs 52–56, the other ops 58–64, and the bound no longer binds)
 template <int OP, int U, bool HALO, bool VAL>
 __global__ __launch_bounds__(RB, OP == FUSE_POST_MAPPED ? 8 : 1) void csr_rowblock_coded_kernel(CODED_PARAMS) {
   const int vb = map_block(bm, blockIdx.x);
