@@ -52,16 +52,24 @@ def pmc_traffic(kernel="spmv", grid=512):
     """HBM/fabric bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC
     summary (profiles/*_summary.json: FETCH_SIZE/WRITE_SIZE in separate passes, corrected as
     MI355X_MICROARCH.md §HBM prescribes).  None if no summary matches this grid."""
+    best = pmc_summary(grid)
+    if not best:
+        return None
+    for r in best[0]["fine_level_kernels"]:
+        if r["kernel"] == kernel:
+            return (r["traffic_bytes"], best[1])
+    return None
+
+
+def pmc_summary(grid=512):
+    """newest committed profile summary for this grid: (dict, file name) or None"""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
-            if d.get("grid") != grid:
-                continue
-            for r in d["fine_level_kernels"]:
-                if r["kernel"] == kernel:
-                    best = (r["traffic_bytes"], os.path.basename(f))
+            if d.get("grid") == grid and d.get("fine_level_kernels"):
+                best = (d, os.path.basename(f))
         except Exception:  # noqa: BLE001
             pass
     return best
@@ -143,51 +151,76 @@ def bundled_cases(mg, args):
     return out
 
 
-def cpu_baseline(mg, args):
-    """CPU oracle V-cycle (port of the same cycle, 1 thread) on a bounded sample: a smaller grid
-    with the hierarchy the device built for it, scaled by the row ratio.  Also times the
-    reference's own Eigen SpMV kernel (oracle/_ref/libref_eigen.so) when that .so travelled."""
-    from oracle import oracle_py as orc
-    import scipy.sparse as sps
-    Ns = args.cpu_grid
+def _oracle_sample(mg, orc, args, Ns, min_cycles, min_seconds, keep_fine=False):
+    """one CPU sample: the hierarchy the device builds for the Ns^3 grid, downloaded once, the oracle's cycle timed on it
+    (1 thread) and compared with the GPU cycle on the same right-hand side"""
     ctx = mg.Context(0)
-    A = ctx.poisson3d(Ns)
-    h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
-    As, Ps = [], []
-    for l in range(h.nlev):
-        rp, ci, v = h.level_A(l).download()
-        rows = h.level_shape(l)[0]
-        As.append(orc.Csr.from_arrays(rows, rows, rp, ci, v))
-        if l < h.nlev - 1:
-            T = h.level_P(l); agg = T.agg(); nf, nc = T.shape
-            r = np.nonzero(agg >= 0)[0]
-            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(r.size), (r, agg[r])), shape=(nf, nc))))
-    n = Ns ** 3
-    b = ctx.vec(n).rand(seed=0).numpy()
-    ho = orc.Hier(As[0], Ps, omega=args.omega, nu1=args.nu1, nu2=args.nu2, As=As)
-    ho.vcycle(b)  # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 12.0:
-        x = ho.vcycle(b); reps += 1
-    t_cycle = (time.perf_counter() - t0) / reps
-    # parity of this very sample against the GPU cycle (cheap, keeps the baseline honest)
-    xg = h.vcycle(ctx.vec(b)).numpy()
-    err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
+    try:
+        A = ctx.poisson3d(Ns)
+        h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+        As, Ps = [], []
+        for l in range(h.nlev):
+            rp, ci, v = h.level_A(l).download()
+            rows = h.level_shape(l)[0]
+            As.append(orc.Csr.from_arrays(rows, rows, rp, ci, v))
+            del rp, ci, v
+            if l < h.nlev - 1:
+                T = h.level_P(l); agg = T.agg(); nf, nc = T.shape
+                has = agg >= 0                                            # P in CSR straight from the aggregate map: row i holds (agg_i, 1.0)
+                prp = np.zeros(nf + 1, dtype=np.int32); np.cumsum(has, out=prp[1:])
+                Ps.append(orc.Csr.from_arrays(nf, nc, prp, agg[has], np.ones(int(prp[-1]))))
+                del agg, has, prp
+        n = Ns ** 3
+        b = ctx.vec(n).rand(seed=0).numpy()
+        ho = orc.Hier(As[0], Ps, omega=args.omega, nu1=args.nu1, nu2=args.nu2, As=As)
+        ho.vcycle(b)  # warm-up (first touch of the work vectors)
+        reps, t0 = 0, time.perf_counter()
+        while reps < min_cycles or time.perf_counter() - t0 < min_seconds:
+            x = ho.vcycle(b); reps += 1
+        t_cycle = (time.perf_counter() - t0) / reps
+        # parity of this very sample against the GPU cycle (cheap, keeps the baseline honest)
+        xg = h.vcycle(ctx.vec(b)).numpy()
+        err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
+        out = {"grid": Ns, "rows": n, "levels": h.nlev, "cycles": reps, "ms_per_cycle": t_cycle * 1e3, "gpu_vs_oracle_rel_err": err}
+        del h, A, ho
+        return out, (As[0] if keep_fine else None)
+    finally:
+        ctx.close()
+
+
+def cpu_baseline(mg, args):
+    """CPU oracle V-cycle (port of the same cycle, 1 thread) AT THE BENCHED SIZE: the hierarchy the device builds for the
+    args.grid^3 operator is downloaded once and >= 2 oracle cycles are timed on it — no scale factor.  A 256^3 sample is kept as
+    a cross-check of the row scaling.  The reference's own Eigen SpMV kernel (oracle/_ref/libref_eigen*.so) is timed on the
+    benched fine operator too, on 1 thread (how the reference ships) and on the host cores of this job."""
+    from oracle import oracle_py as orc
+    Ns = args.cpu_grid if args.cpu_grid > 0 else args.grid
+    full, A0 = _oracle_sample(mg, orc, args, Ns, 2, 6.0 if Ns >= 384 else 12.0, keep_fine=True)
     scale = (args.grid / Ns) ** 3
-    out = {"value": 1.0 / (t_cycle * scale), "unit": "V-cycles/s", "cores": 1, "kind": "port",
-           "sample": f"oracle V({args.nu1},{args.nu2}) cycle on a {Ns}^3 grid ({n} rows, {h.nlev} levels built on device), "
-                     f"{reps} cycles of {t_cycle * 1e3:.1f} ms, scaled by the row ratio x{scale:.0f} to {args.grid}^3",
-           "sample_ms_per_cycle": t_cycle * 1e3, "gpu_vs_oracle_rel_err_on_sample": err}
-    # reference's own SpMV kernel (Eigen 3.3.4, 1 thread) on the sample's fine operator
+    n = Ns ** 3
+    out = {"value": 1.0 / (full["ms_per_cycle"] * 1e-3 * scale), "unit": "V-cycles/s", "cores": 1, "kind": "port",
+           "sample": f"oracle V({args.nu1},{args.nu2}) cycle on the {Ns}^3 grid ({n} rows, {full['levels']} levels built on device, downloaded once), "
+                     f"{full['cycles']} cycles of {full['ms_per_cycle']:.1f} ms after one warm-up cycle"
+                     + ("" if scale == 1.0 else f", scaled by the row ratio x{scale:.0f} to {args.grid}^3"),
+           "sample_ms_per_cycle": full["ms_per_cycle"], "gpu_vs_oracle_rel_err_on_sample": full["gpu_vs_oracle_rel_err"]}
+    if Ns > 256 and not args.no_cpu_cross:
+        try:       # cross-check of the row scaling the earlier rounds reported (256^3 x 8)
+            cross, _ = _oracle_sample(mg, orc, args, 256, 3, 3.0)
+            cross["scaled_to_benched_grid_vcycles_per_s"] = 1.0 / (cross["ms_per_cycle"] * 1e-3 * (Ns / 256) ** 3)
+            out["cross_check_256"] = cross
+        except Exception as e:  # noqa: BLE001
+            out["cross_check_256"] = {"error": repr(e)}
+    # reference's own SpMV kernel (Eigen 3.3.4) on the benched fine operator
     so = os.path.join(REPO, "oracle", "_ref", "libref_eigen.so")
-    rp, ci, v = As[0].rowptr, As[0].col, As[0].val
+    rp, ci, v = A0.rowptr, A0.col, A0.val
     nnz = len(ci)
+    out["spmv_sample"] = f"{Ns}^3 fine operator ({n} rows, {nnz} nnz)"
     xs = np.random.default_rng(0).random(n); y = np.empty(n)
     if os.path.exists(so):
         L = C.CDLL(so)
         L.ref_eigen_spmv.restype = C.c_double
         L.ref_eigen_spmv.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        t = L.ref_eigen_spmv(n, n, nnz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, xs.ctypes.data, y.ctypes.data, 5)
+        t = L.ref_eigen_spmv(n, n, nnz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data, xs.ctypes.data, y.ctypes.data, 3)
         out["spmv_eigen_reference_gbps"] = spmv_bytes(n, nnz) / t / 1e9
         out["spmv_eigen_reference_ms"] = t * 1e3
     so_omp = os.path.join(REPO, "oracle", "_ref", "libref_eigen_omp.so")
@@ -204,17 +237,15 @@ def cpu_baseline(mg, args):
         except Exception as e:  # noqa: BLE001
             out["spmv_eigen_reference_all_cores_error"] = repr(e)
     t0 = time.perf_counter()
-    for _ in range(5):
-        As[0].spmv(xs)
-    t = (time.perf_counter() - t0) / 5
+    for _ in range(3):
+        A0.spmv(xs)
+    t = (time.perf_counter() - t0) / 3
     out["spmv_oracle_port_gbps"] = spmv_bytes(n, nnz) / t / 1e9
     try:
         out["host_cpu"] = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         out["host_nproc"] = os.cpu_count()
     except Exception:  # noqa: BLE001
         pass
-    del h, A
-    ctx.close()
     return out
 
 
@@ -243,7 +274,9 @@ def parse_args():
     ap.add_argument("--npass", type=int, default=2)
     ap.add_argument("--tou", type=float, default=8.0)
     ap.add_argument("--coarse-rows", type=int, default=2500)
-    ap.add_argument("--cpu-grid", type=int, default=256, help="grid of the CPU-baseline sample (oracle V-cycle, 1 thread): 256^3 = 1/8 of the rows of the headline grid")
+    ap.add_argument("--cpu-grid", type=int, default=0, help="grid of the CPU-baseline sample (oracle V-cycle, 1 thread); 0 = the benched grid itself (no scale factor)")
+    ap.add_argument("--no-cpu-cross", action="store_true", help="skip the 256^3 cross-check sample of the CPU baseline")
+    ap.add_argument("--optin", action="store_true", help="also run the opt-in value-pattern leg (valcode=1; builds a second hierarchy; never the headline)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=20)
     return ap.parse_args()
@@ -347,7 +380,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_step = elapsed / args.steps * 1e3
     vbytes = h.vcycle_bytes
-    log(f"V-cycle {ms_step:.3f} ms ({args.steps / elapsed:.2f} /s), algorithmic {vbytes / 1e9:.2f} GB/cycle = {vbytes / elapsed * args.steps / 1e9:.0f} GB/s")
+    log(f"V-cycle {ms_step:.3f} ms ({args.steps / elapsed:.2f} /s)")
 
     # A/B inside the same process: the unfused one-kernel-per-step form of the same cycle
     ctx.set_option("fuse", 0)
@@ -391,6 +424,15 @@ def main():
     del xk
 
     traffic, traffic_src = pmc_traffic("spmv", N) or (None, None)
+    # what crosses HBM in one launch of the dominant kernel: the PMC measurement of the committed profile of this build, else the
+    # bytes the kernel streams by construction (8 B per entry + 21 B per row + tables), else the CSR byte count (plain CSR kernel)
+    phys_bytes = traffic or streamed or spmv_bytes(n, nnz)
+    phys_basis = (f"PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of {traffic_src} / this run's ms_per_launch" if traffic else
+                  ("bytes the kernel streams by construction / this run's ms_per_launch (no committed PMC summary for this grid)" if streamed else
+                   "CSR bytes / this run's ms_per_launch (plain CSR kernel)"))
+    summ = pmc_summary(N)
+    cyc = (summ[0].get("vcycle") if summ else None) or {}
+    cyc_bytes = cyc.get("traffic_bytes")
     out = {
         "metric": "V-cycles/sec + fine-level SpMV HBM GB/s, 512³ 7-pt Poisson, 1/2/4/8 GPU",
         "value": args.steps / elapsed, "unit": "V-cycles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -400,26 +442,31 @@ def main():
                                f"hierarchy built on device by pairwise aggregation ktg={args.ktg} npass={args.npass} tou={args.tou}",
                    "grid": N, "rows": n, "nnz": nnz, "levels": levels, "parallelism": "1 GPU", "setup_seconds": t_setup,
                    "first_cycle_seconds_incl_operand_setup": t_operands},
-        # what crosses HBM per second in the fine-level SpMV (PMC traffic of the committed profile, else the bytes the kernel streams by
-        # construction) — the algorithmic §8d-d3 rate, which counts the never-read column index, is spmv_algorithmic_gbps / roofline.achieved
-        "spmv_hbm_gbps": gbps(traffic, ms_spmv) if traffic else (gbps(streamed, ms_spmv) if streamed else spmv_gbps),
-        "spmv_algorithmic_gbps": spmv_gbps,
-        "roofline": {"bound": "hbm", "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": spmv_gbps / HBM_PEAK_GBPS,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     # physical rate: bytes that crossed the fabric (PMC) / this run's launch time — beside the algorithmic figure above
-                     "hbm_gbps": gbps(traffic, ms_spmv) if traffic else None, "hbm_frac": gbps(traffic, ms_spmv) / HBM_PEAK_GBPS if traffic else None,
+        "spmv_hbm_gbps": gbps(phys_bytes, ms_spmv),
+        "spmv_effective_csr_gbps": spmv_gbps,
+        # roofline of the dominant kernel = what crosses HBM per second against the 8 TB/s peak.  The SURVEY §8d-d3 figure (CSR bytes /
+        # time) is kept under its own name: the pattern-coded kernel never reads the column-index array, so that figure is an
+        # effective rate and can exceed the peak.
+        "roofline": {"bound": "hbm", "achieved": gbps(phys_bytes, ms_spmv), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": gbps(phys_bytes, ms_spmv) / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "basis": phys_basis,
                      "kernel": "csr_rowblock_coded_kernel<SPMV> (fine level; CSR SpMV with pattern-coded column index)",
-                     "algorithmic_bytes_per_launch": spmv_bytes(n, nnz), "ms_per_launch": ms_spmv,
-                     "note": "achieved/frac = SURVEY §8d-d3 CSR bytes (12·nnz + 20·n + 4) / time — an EFFECTIVE rate: the kernel rebuilds the column "
-                             "index from a per-row-block pattern table and streams 8 B per entry + 1 B per row, so fewer bytes cross HBM than "
-                             "the numerator counts; hbm_gbps/hbm_frac (PMC traffic of the committed profile / this run's time) and streamed_* are "
-                             "the physical rates; csr_kernel = the same product with the plain 12 B/entry CSR kernel (all of it streamed)",
+                     "ms_per_launch": ms_spmv,
+                     "effective_csr_bytes_per_launch": spmv_bytes(n, nnz), "effective_csr_gbps": spmv_gbps, "effective_csr_frac": spmv_gbps / HBM_PEAK_GBPS,
+                     "note": "achieved/frac = bytes that cross HBM in one launch / launch time (HIP events on the kernel's stream, this run) / 8 TB/s. "
+                             "effective_csr_* = SURVEY §8d-d3 CSR bytes (12·nnz + 20·n + 4) / time: the kernel rebuilds the column index from a per-row-block "
+                             "pattern table and streams 8 B per entry + 1 B per row, so fewer bytes cross HBM than that count; csr_kernel = the same "
+                             "product with the plain 12 B/entry CSR kernel, which streams all of them",
                      "streamed_bytes_per_launch": streamed, "streamed_gbps": gbps(streamed, ms_spmv) if streamed else None,
-                     "streamed_frac": gbps(streamed, ms_spmv) / HBM_PEAK_GBPS if streamed else None,
                      "csr_kernel": {"ms": ms_spmv_csr, "gbps": gbps(spmv_bytes(n, nnz), ms_spmv_csr), "frac": gbps(spmv_bytes(n, nnz), ms_spmv_csr) / HBM_PEAK_GBPS},
-                     "other_kernels": {"residual": {"ms": ms_res, "gbps": gbps(residual_bytes(n, nnz), ms_res)},
-                                       "jacobi": {"ms": ms_jac, "gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
-                     "vcycle_algorithmic_gb": vbytes / 1e9, "vcycle_gbps": vbytes / (elapsed / args.steps) / 1e9,
+                     "other_kernels": {"residual": {"ms": ms_res, "effective_csr_gbps": gbps(residual_bytes(n, nnz), ms_res)},
+                                       "jacobi": {"ms": ms_jac, "effective_csr_gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
+                     # the cycle: PMC bytes of every dispatch of one cycle in the same profile set, over this run's ms_per_step (<= peak by
+                     # construction); the §8d byte count of the cycle's operations beside it as an effective figure
+                     "vcycle_hbm_gb": cyc_bytes / 1e9 if cyc_bytes else None,
+                     "vcycle_hbm_gbps": cyc_bytes / (ms_step * 1e-3) / 1e9 if cyc_bytes else None,
+                     "vcycle_hbm_frac": cyc_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if cyc_bytes else None,
+                     "vcycle_dispatches_in_profile": cyc.get("dispatches"), "vcycle_kernel_ms_in_profile": cyc.get("kernel_ms"),
+                     "vcycle_effective_csr_gb": vbytes / 1e9,
                      "vcycle_ms_unfused_form": ms_unfused, "grouped_pre_pass": [h.group_info(l) for l in range(min(h.nlev - 1, 4))]},
         "solve_check": {"one_cycle_residual_reduction": r1 / r0, "bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol,
                         "bicgstab_seconds": t_solve,
@@ -430,11 +477,12 @@ def main():
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
-    try:
-        out["optin_value_patterns"] = optin_value_patterns(mg, args, N)
-        log(f"opt-in value patterns (not the headline): {out['optin_value_patterns']['vcycles_per_s']:.1f} V-cycles/s, SpMV {out['optin_value_patterns']['spmv_ms']:.3f} ms")
-    except Exception as e:  # noqa: BLE001
-        log("opt-in value-pattern leg failed:", repr(e))
+    if args.optin:       # a second hierarchy for a figure that only constant-coefficient operators see: not part of the default run
+        try:
+            out["optin_value_patterns"] = optin_value_patterns(mg, args, N)
+            log(f"opt-in value patterns (not the headline): {out['optin_value_patterns']['vcycles_per_s']:.1f} V-cycles/s, SpMV {out['optin_value_patterns']['spmv_ms']:.3f} ms")
+        except Exception as e:  # noqa: BLE001
+            log("opt-in value-pattern leg failed:", repr(e))
     try:
         out["bundled_matrices"] = bundled_cases(mg, args)
     except Exception as e:  # noqa: BLE001

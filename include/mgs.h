@@ -240,15 +240,14 @@ int mgs_hier_set_halo_exchange(mgs_hier *h, mgs_halo_fn fn, void *user);
  * of the rows of a plane-sharded stencil operator.  Falls back to fn for levels whose halo
  * readers are not a prefix + suffix of the row range.                                          */
 int mgs_hier_set_halo_exchange_split(mgs_hier *h, mgs_halo_fn begin, mgs_halo_fn end, void *user);
-/* Payload exchange of the fused cycle passes on a row shard.  kind 0: the peers need x1 = wd∘b of the
- * rows they see as halo (a = wd, b = the right-hand side); kind 1: they need (P e_c) = e_c[agg] of those
- * rows (a = e_c, b = agg as const int*).  phase 0 packs (mgs_halo_pack_prod / mgs_halo_pack_pe) and
- * starts the exchange into halo_out (n_halo doubles), phase 1 waits for it.  Without this callback a
- * sharded hierarchy runs the one-kernel-per-step form.                                            */
+/* Halo exchange of the fused cycle passes on a row shard (kind is always 2: plain values).  The callee delivers, for every halo
+ * slot of `level`, the entry of the owner's vector `a` (owned entries of that level on every rank) that the slot stands for, into
+ * halo_out — a payload buffer (pre pass: a = the right-hand side; the owners' ωD⁻¹ sits in Â's halo columns since setup) or the halo
+ * room of the vector itself (post pass: a = e_c of the coarse level, level = that coarse level).  b is NULL.  phase 0 packs
+ * (mgs_halo_pack) and starts the exchange, phase 1 waits for it; the library launches the interior row blocks in between.
+ * Without this callback (and without a native plan) a sharded hierarchy runs the one-kernel-per-step form.                */
 typedef int (*mgs_halo_fused_fn)(void *user, int level, int kind, const void *a, const void *b, void *halo_out, int phase);
 int mgs_hier_set_halo_exchange_fused(mgs_hier *h, mgs_halo_fused_fn fn, void *user);
-int mgs_halo_pack_prod(mgs_ctx *ctx, const void *wd_dev, const void *b_dev, const int *send_idx_dev, int64_t n_send, double *send_buf_dev);
-int mgs_halo_pack_pe(mgs_ctx *ctx, const void *ec_dev, const void *agg_dev, const int *send_idx_dev, int64_t n_send, double *send_buf_dev);
 
 /* Building blocks of a row-sharded hierarchy (one process per GPU; orchestration in
  * multigridsolver_amd/dist.py).  mgs_aggregate_shard: pairwise aggregation of the OWNED
@@ -304,7 +303,12 @@ int mgs_csr_set_origin(mgs_csr *A, const int *origin_host);
  *     for that level.  comm = NULL removes the plan.
  *   mgs_hier_set_native_tail: the coarsest sharded level is all-gathered (ncclAllGather) and solved by `tail`, an
  *     unsharded hierarchy on the globally assembled operator replicated on every rank; nlocs = rows per rank.
- *   mgs_hier_native_halo: one plain halo exchange of the level-`level` vector x_dev (owned entries + halo room).  */
+ *   mgs_hier_native_halo: one plain halo exchange of the level-`level` vector x_dev (owned entries + halo room).
+ *   mgs_hier_native_send_segments / mgs_hier_set_native_recv_segments: pack-free exchanges.  Where a peer's rows are a few
+ *     contiguous ranges (plane shards: one), they are sent straight from the source vector, one ncclSend per range, and the
+ *     peer posts one ncclRecv per range.  Each rank reads what it will send (ranges per peer + their lengths; returns the number
+ *     of lengths), the host side ships the lengths to the peers, and every rank installs what it will receive — a COLLECTIVE
+ *     step: from that call on the rank itself sends ranges.  Without it every exchange goes through the pack kernel.  */
 #define MGS_COMM_ID_BYTES 128
 typedef struct mgs_comm mgs_comm;
 int mgs_comm_unique_id(mgs_ctx *ctx, const char *librccl_path, void *id_out);
@@ -314,6 +318,8 @@ int mgs_comm_size(const mgs_comm *c, int *world, int *rank);
 int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int *send_idx, const int *send_counts, const int *recv_counts);
 int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs);
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev);
+int mgs_hier_native_send_segments(const mgs_hier *h, int level, int *nseg_per_peer, int *seglens, int cap);
+int mgs_hier_set_native_recv_segments(mgs_hier *h, int level, const int *nseg_per_peer, const int *seglens);
 /* inner products of the Krylov solvers summed over the ranks with ncclAllReduce on the context's stream (NULL: off;
  * takes precedence over the mgs_ctx_set_allreduce callback) */
 int mgs_ctx_set_native_allreduce(mgs_ctx *ctx, mgs_comm *c);

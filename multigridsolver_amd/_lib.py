@@ -45,6 +45,8 @@ PROTOTYPES = {
     "mgs_hier_set_native_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_set_native_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_native_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mgs_hier_native_send_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "mgs_hier_set_native_recv_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mgs_ctx_set_native_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgs_csr_optimize": (C.c_int, [C.c_void_p]),
     "mgs_hier_fused_info": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
@@ -107,8 +109,6 @@ PROTOTYPES = {
     "mgs_xfer_from_agg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(C.c_void_p)]),
     "mgs_hier_set_coarse_solver": (C.c_int, [C.c_void_p, COARSE_FN, C.c_void_p]),
     "mgs_hier_set_halo_exchange_fused": (C.c_int, [C.c_void_p, HALO_FUSED_FN, C.c_void_p]),
-    "mgs_halo_pack_prod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "mgs_halo_pack_pe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgs_hier_set_halo_exchange_split": (C.c_int, [C.c_void_p, HALO_FN, HALO_FN, C.c_void_p]),
     "mgs_ctx_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mgs_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p]),

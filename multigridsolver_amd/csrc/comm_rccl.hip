@@ -1,7 +1,8 @@
 // comm_rccl.hip — native RCCL transport of the row-sharded cycle (one process per GPU, xGMI point-to-point).
 //
-// The exchange step of the path is a neighbour exchange of halo values: a pack kernel, then one
-// RCCL group of ncclSend/ncclRecv to the peers that own halo columns — enqueued by the C++ cycle itself on the
+// The exchange step of the path is a neighbour exchange of halo values: one RCCL group of
+// ncclSend/ncclRecv to the peers that own halo columns — straight from the source vector where a peer's rows are a few
+// contiguous ranges (plane shards), behind a pack kernel otherwise — enqueued by the C++ cycle itself on the
 // context's stream, so a sharded cycle needs no host callback and no cross-stream dependency per exchange.  The
 // replicated coarse tail gathers its right-hand side with one ncclAllGather.
 //
@@ -93,17 +94,17 @@ int mgs_comm_size(const mgs_comm *c, int *world, int *rank) { if (world) *world 
 
 }  // extern "C"
 
-// neighbour exchange on the context's stream: peer p gets scnt[p] doubles from send (packed peer after peer) and
-// delivers rcnt[p] doubles into recv (peer after peer); zero counts issue nothing
-int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *recv, const int *rcnt) {
+// neighbour exchange on the context's stream: one RCCL group of sends and receives.  The ops addressed to one peer are matched with
+// that peer's ops in posting order (k-th send to p ↔ p's k-th receive from this rank), so a peer's payload may travel as several
+// contiguous ranges taken straight from the source vector.  Zero counts issue nothing.
+int mgs_comm_exchange_ops(mgs_comm *c, const mgs_xfer_op *ops, int nops) {
   hipStream_t s = c->ctx->stream;
   MGS_NCCL(c, c->GroupStart());
-  size_t so = 0, ro = 0;
   ncclResult_t bad = ncclSuccess;
-  for (int p = 0; p < c->world && bad == ncclSuccess; ++p) {
-    if (scnt[p]) bad = c->Send(send + so, (size_t)scnt[p], ncclDouble, p, c->comm, s);
-    if (rcnt[p] && bad == ncclSuccess) bad = c->Recv(recv + ro, (size_t)rcnt[p], ncclDouble, p, c->comm, s);
-    so += (size_t)scnt[p]; ro += (size_t)rcnt[p];
+  for (int q = 0; q < nops && bad == ncclSuccess; ++q) {
+    const mgs_xfer_op &o = ops[q];
+    if (!o.count) continue;
+    bad = o.sptr ? c->Send(o.sptr, o.count, ncclDouble, o.peer, c->comm, s) : c->Recv(o.rptr, o.count, ncclDouble, o.peer, c->comm, s);
   }
   const ncclResult_t end = c->GroupEnd();          // always closed, also after a failed post
   if (bad != ncclSuccess) return mgs_fail(c->ctx, MGS_ERR_STATE, "ncclSend/ncclRecv failed: %s", c->GetErrorString(bad));

@@ -170,23 +170,18 @@ __global__ void scale_vals_kernel(int n, const int *__restrict__ rowptr, const i
                                   const double *__restrict__ wd, double *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) { const int c = col[k]; out[k] = c < n ? val[k] * wd[c] : val[k]; }   // halo column: the payload is x1 itself
+  // row shards: wd's halo part holds the owners' ω/a_jj (fetched once at setup), so a halo column is scaled like an owned one and
+  // the pre pass's payload is the peers' raw right-hand side
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = val[k] * wd[col[k]];
 }
-__global__ void map_cols_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ agg, int n_coarse,
-                                int *__restrict__ out) {
+__global__ void map_cols_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ cmap, int *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) { const int c = col[k]; out[k] = c < n ? agg[c] : n_coarse + (c - n); }   // halo column: payload slot
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) out[k] = cmap[col[k]];
 }
-
-// halo payloads of the fused passes on row shards: the peer needs x1 = wd∘b resp. (Pe) = e_c[agg] of my rows
-__global__ void gather_prod_kernel(const double *__restrict__ wd, const double *__restrict__ b, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int r = idx[i]; out[i] = wd[r] * b[r]; }
-}
-__global__ void gather_pe_kernel(const double *__restrict__ ec, const int *__restrict__ agg, const int *__restrict__ idx, int64_t n, double *__restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int a = agg[idx[i]]; out[i] = a >= 0 ? ec[a] : 0.0; }
+__global__ void concat_i32_kernel(const int *__restrict__ a, int na, const int *__restrict__ b, int nb, int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) out[i] = a[i]; else if (i < na + nb) out[i] = b[i - na];
 }
 
 // ------------------------------------------------------------------ reductions
@@ -618,18 +613,13 @@ int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out) 
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
-int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int *out) {
-  if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, agg, n_coarse, out);
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *cmap, int *out) {
+  if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, cmap, out);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
-int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out) {
-  if (n) hipLaunchKernelGGL(gather_prod_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, wd, b, idx, n, out);
-  MGS_HIP(ctx, hipGetLastError());
-  return MGS_OK;
-}
-int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out) {
-  if (n) hipLaunchKernelGGL(gather_pe_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, ec, agg, idx, n, out);
+int k_concat_i32(mgs_ctx *ctx, const int *a, int na, const int *b, int nb, int *out) {
+  if (na + nb) hipLaunchKernelGGL(concat_i32_kernel, dim3(mgs_grid(na + nb, TB)), dim3(TB), 0, ctx->stream, a, na, b, nb, out);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

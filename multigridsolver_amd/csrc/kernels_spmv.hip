@@ -48,7 +48,8 @@ __device__ __forceinline__ void st_stream(double *p, double v, bool nt) {
 
 // Value slice of a row block straight from global memory into LDS (no VGPR in between, so nothing for the register allocator to
 // keep alive or spill): piece p = 64 pairs = 1 KiB, wave w takes pieces w, w + 4, w + 8, w + 12; lane l of a piece moves pair 64p + l.
-// Covers up to 1024 pairs (2048 doubles); the caller checks that.  The workgroup barrier that follows waits for the transfers.
+// Covers up to 1024 pairs (2048 doubles); the caller checks that.  The caller waits for its own transfers (s_waitcnt vmcnt(0), explicit)
+// before the workgroup barrier that publishes the slice.
 __device__ __forceinline__ void stage_pairs_dma(const double *__restrict__ src, double *lds, int npairs, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -289,7 +290,7 @@ __device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc,
     if (OP == FUSE_PRE) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        if (q < rem) { const int c = csrc[k + q]; xv[q] = c < n_owned ? wd[c] * bvec[c] : hv[c - n_owned]; } else xv[q] = 0.0;
+        if (q < rem) { const int c = csrc[k + q]; xv[q] = wd[c] * (c < n_owned ? bvec[c] : hv[c - n_owned]); } else xv[q] = 0.0;   // row shards: wd covers the halo columns, hv = the peers' raw b
       }
     } else if (OP == FUSE_POST_MAPPED) {
       int av[8];
@@ -300,9 +301,9 @@ __device__ __forceinline__ double fused_row_sum(const double *__restrict__ vsrc,
     } else {
       int av[8], cv[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { cv[q] = q < rem ? csrc[k + q] : -1; av[q] = (cv[q] >= 0 && cv[q] < n_owned) ? agg[cv[q]] : -1; }
+      for (int q = 0; q < 8; ++q) { cv[q] = q < rem ? csrc[k + q] : -1; av[q] = cv[q] >= 0 ? agg[cv[q]] : -1; }   // agg: coarse column of every local column (row shards: halo slots too)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : (cv[q] >= n_owned ? hv[cv[q] - n_owned] : 0.0);
+      for (int q = 0; q < 8; ++q) xv[q] = av[q] >= 0 ? ec[av[q]] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q < rem) s += vsrc[k + q] * xv[q];
@@ -919,6 +920,9 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
         if (tid < tlen) tw = tab[t0 + tid];
         if (tid < tlen) ints[tid] = tw;
         for (int c = tid + RB; c < tlen; c += RB) ints[c] = tab[t0 + c];
+        // LDS-DMA transfers are vector-memory operations of the issuing wave: the workgroup barrier's fence does not cover them, so every
+        // wave drains its own before it arrives (spelled out; the compiler happens to place the same wait in front of s_barrier today)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else if (coded) {
 #pragma unroll 4
         for (int c = tid; c < nch; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(val + start + 2 * c);
@@ -1631,7 +1635,7 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
                            const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi, int gap_at, int gap_len) {
   mgs_ctx *ctx = A->ctx;
   if (A->rows == 0 || blk_hi <= blk_lo) return MGS_OK;
-  if (A->lds_cap <= 0 || (which != FUSE_POST_MAPPED && A->rows != A->cols && !hv)) return MGS_ERR_STATE;   // (the mapped operand may be A·P: n × n_c)
+  if (A->lds_cap <= 0 || (which == FUSE_PRE && A->rows != A->cols && !hv)) return MGS_ERR_STATE;   // (row shards: the pre pass reads its halo columns from the payload; the post passes gather e_c, halo room included)
   BlockMap bm;
   bm.gap_at = gap_at; bm.gap_len = gap_len;
   bm.base = blk_lo; bm.nblocks = blk_hi - blk_lo;

@@ -59,6 +59,7 @@ struct mgs_ctx {
   int opt_stage_unroll = 1;   // row-block kernels stage their value slice without a loop in front of the barrier (predicated 16-byte loads / LDS-DMA): −4 … −7 % per cycle
   int opt_blas1_pairs = 1;    // ... pairs per lane of those kernels: 1 = one-shot workgroups (0: capped persistent grid, k: k pairs per lane)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
+  int opt_kcycle_energy = 0;  // K-cycle coefficients from energy inner products (flexible-CG form; SPD operators) instead of the GCR form of the paper
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:
                               // a graph with cross-stream edges costs 0.48 ms of host time per launch and 1.219 vs 1.155 ms per cycle — off by default)
@@ -125,6 +126,8 @@ struct mgs_xfer {
   int *cptr = nullptr;     // n_coarse+1: member list offsets (Pᵀ rowptr)
   int *members = nullptr;  // nnz(P): fine rows sorted by aggregate (Pᵀ col)
   int *corigin = nullptr;  // n_coarse: origin (see mgs_csr) of every aggregate, handed to the coarse operator
+  int *halo_cmap = nullptr;   // row shards (mgs_galerkin_shard): coarse column (n_coarse + coarse halo slot, −1 = not aggregated) of every fine halo slot
+  int n_halo_fine = 0, n_halo_coarse = 0;
   int64_t nnz = 0;
   // general form
   mgs_csr *P = nullptr, *Pt = nullptr;
@@ -132,7 +135,8 @@ struct mgs_xfer {
 
 // native RCCL transport (comm_rccl.hip)
 struct mgs_comm;
-int mgs_comm_exchange(mgs_comm *c, const double *send, const int *scnt, double *recv, const int *rcnt);
+struct mgs_xfer_op { const double *sptr; double *rptr; size_t count; int peer; };   // one ncclSend (sptr) or ncclRecv (rptr)
+int mgs_comm_exchange_ops(mgs_comm *c, const mgs_xfer_op *ops, int nops);             // one group; ops of a peer are matched in order
 int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count);
 int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count);
 bool mgs_comm_capturable(const mgs_comm *c);   // false for the file-based stand-in of the tests (host-synchronous calls)
@@ -143,7 +147,15 @@ struct mgs_native_plan {
   std::vector<int> scnt, rcnt;      // per peer
   int64_t ns = 0, nr = 0;
   double *sendbuf = nullptr;        // device, ns doubles
+  // Pack-free form: a peer's send list that is a few contiguous row ranges (plane shards: one) is sent straight from the source
+  // vector, one ncclSend per range, and the peer posts one ncclRecv per range — no pack kernel.  The ranges a rank sends are
+  // its own decision (sseg, from send_idx); what it receives it is told by its peers (rseg, shipped by the host side at setup:
+  // mgs_hier_native_send_segments → mgs_hier_set_native_recv_segments, which also switches this rank's sends to ranges).
+  std::vector<std::vector<int>> sseg_start, sseg_len, rseg_len;   // per peer
+  bool seg_ok = false;      // every peer's send list splits into at most MGS_MAX_SEG ranges
+  bool use_seg = false;     // receive segmentation installed on this rank (collective call): sends go out as ranges
 };
+constexpr int MGS_MAX_SEG = 8;
 struct mgs_hier;
 // replicated coarse tail driven natively: all-gather of the right-hand side, tail cycle, own slice back
 struct mgs_native_tail {
@@ -177,8 +189,10 @@ struct mgs_level {
   int n = 0;              // owned rows
   int n_ext = 0;          // owned + halo
   mgs_vec *dinv = nullptr, *r = nullptr, *tmp = nullptr;
-  mgs_vec *wd = nullptr;       // ω·dinv (fused passes)
-  mgs_vec *hbuf = nullptr;     // halo payload of the fused passes (row shards)
+  mgs_vec *wd = nullptr;       // ω·dinv (fused passes); row shards: n_ext entries, the halo part holds the owners' values
+  mgs_vec *hbuf = nullptr;     // halo payload of the fused pre pass (row shards): the peers' raw b of the rows this shard sees as halo
+  bool halo_dinv = false;      // row shards: dinv's halo part has been fetched from the owners (one exchange at setup)
+  int *cmap_ext = nullptr;     // row shards: coarse column of every local column (owned: agg, halo slot: T->halo_cmap), n_ext ints
   double *val_wd = nullptr;    // setup-time operand of the fused pre pass: a_ij·wd_j, so A·(wd∘b) = Â·b needs one gather
   int *col_agg = nullptr;      // setup-time operand of the fused post pass: agg[col_ij], so (A·Pe) gathers e_c directly
   mgs_rowcode *code_agg = nullptr;   // pattern code of col_agg (offsets from agg[row])
@@ -271,10 +285,9 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
 int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const double *bvec, const double *xin, const int *agg,
                            const double *ec, double *out, double *out2, const double *hv, int blk_lo, int blk_hi,
                            int gap_at = 0x7fffffff, int gap_len = 0);
-int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);            // halo columns (>= rows) keep their value
-int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *agg, int n_coarse, int *out);        // halo column c -> n_coarse + (c − rows)
-int k_gather_prod(mgs_ctx *ctx, const double *wd, const double *b, const int *idx, int64_t n, double *out);
-int k_gather_pe(mgs_ctx *ctx, const double *ec, const int *agg, const int *idx, int64_t n, double *out);
+int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);            // out_k = a_k·wd[col_k] (row shards: wd covers the halo columns too)
+int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *cmap, int *out);                     // out_k = cmap[col_k]
+int k_concat_i32(mgs_ctx *ctx, const int *a, int na, const int *b, int nb, int *out);
 int mgs_plan_csr(mgs_csr *A);
 int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out,
                       const double *val = nullptr);
@@ -319,7 +332,7 @@ int k_transpose(const mgs_csr *A, mgs_csr **out);
 // (setup_agmg.hip)
 int k_exclusive_scan_i32(mgs_ctx *ctx, const int *in, int *out, int64_t n, int64_t *total_host);
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
-int k_build_ap(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
+int k_build_ap(const mgs_csr *A, const mgs_xfer *T, const int *cmap_ext, int ncols, mgs_csr **out);   // cmap_ext = NULL: square level, T->agg
 int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out);
 int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_host, mgs_xfer **out);
 int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);

@@ -530,17 +530,19 @@ int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_
 }
 int k_galerkin_agg(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) { return k_galerkin_agg_ext(A, T, nullptr, 0, out); }
 
-// A·P for an aggregation P (rows of A, one column per aggregate; on a row shard the halo columns keep one column each behind
-// them: n_coarse + slot): the entries of a row that fall into one aggregate are summed in ascending column order, entries of
-// columns outside every aggregate drop out.  Setup-time operand of the fused post pass (A·(P e_c) = (A·P) e_c).
-int k_build_ap(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
+// A·P for an aggregation P (rows of A, one column per aggregate): the entries of a row that fall into one aggregate are summed in
+// ascending column order, entries of columns outside every aggregate drop out.  Setup-time operand of the fused post pass
+// (A·(P e_c) = (A·P) e_c).  On a row shard cmap_ext maps every local column — owned rows through agg, halo slots through the coarse
+// halo map of the shard's Galerkin product — to the coarse level's local numbering (n_coarse + coarse halo slot), so the halo
+// columns of A·P are the coarse level's own halo columns and the post pass's payload is the plain halo exchange of e_c.
+int k_build_ap(const mgs_csr *A, const mgs_xfer *T, const int *cmap_ext, int ncols, mgs_csr **out) {
   mgs_ctx *ctx = A->ctx;
   MGS_CHECK(ctx, T->aggregation && T->n_fine == A->rows && A->rows <= A->cols, MGS_ERR_INVALID, "A·P: shape mismatch");
-  if (A->rows == A->cols) return galerkin_core(A, A->rows, nullptr, nullptr, T->agg, T->n_coarse, out);
-  DevBuf cm;
-  MGS_TRY(dalloc<int>(ctx, cm, (size_t)A->cols));
-  hipLaunchKernelGGL(colmap_ext_kernel, dim3(mgs_grid(A->cols, TB)), dim3(TB), 0, ctx->stream, A->rows, A->cols, T->n_coarse, T->agg, (const int *)nullptr, cm.as<int>());
-  return galerkin_core(A, A->rows, nullptr, nullptr, cm.as<int>(), T->n_coarse + (A->cols - A->rows), out);
+  if (!cmap_ext) {
+    MGS_CHECK(ctx, A->rows == A->cols, MGS_ERR_INVALID, "A·P of a row shard needs the coarse map of its halo columns");
+    return galerkin_core(A, A->rows, nullptr, nullptr, T->agg, T->n_coarse, out);
+  }
+  return galerkin_core(A, A->rows, nullptr, nullptr, cmap_ext, ncols, out);
 }
 
 // general P (not an aggregation): host Gustavson product, as the reference does with Eigen on

@@ -267,7 +267,7 @@ class ShardedHierarchy:
         self.h = core.Hierarchy(A_local, omega, nu1, nu2)
         self.smoother = (omega, nu1, nu2)
         self.tail = None
-        self._views, self._bufs, self._keep, self._xc, self._pending = {}, {}, [], {}, {}
+        self._views, self._bufs, self._keep, self._xc, self._pending, self._xv = {}, {}, [], {}, {}, {}
         self.n_exchanges = 0
         self.overlap_min_rows = 1_000_000
 
@@ -327,7 +327,9 @@ class ShardedHierarchy:
             w.wait()
 
     def _exchange_fused(self, level, kind, a_ptr, b_ptr, out_ptr, phase):
-        """payload of the fused passes: kind 0 → wd[idx]*b[idx], kind 1 → e_c[agg[idx]]; lands in out_ptr"""
+        """halo values of the fused passes: out_ptr[slot] = the owner's a_ptr[row the slot stands for], on `level`'s plan (kind 2: plain
+        values — the pre pass asks for the right-hand side into its payload buffer, the post pass for the coarse level's e_c into that
+        vector's own halo room).  phase 0 packs and starts, phase 1 waits."""
         if phase == 1:
             w = self._pending.pop(("f", level), None)
             if w is not None:
@@ -339,8 +341,10 @@ class ShardedHierarchy:
             return
         buf = self._bufs[level]
         if ns:
-            fn = lib().mgs_halo_pack_prod if kind == 0 else lib().mgs_halo_pack_pe
-            check(fn(self.ctx.h, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_void_p(plan.dev_send_idx.data_ptr()), ns, C.c_void_p(buf.data_ptr())), self.ctx.h)
+            xv = self._xv.get((level, a_ptr))
+            if xv is None:
+                xv = self._xv[(level, a_ptr)] = core.Vec.wrap(self.ctx, a_ptr, plan.n_loc)
+            check(lib().mgs_halo_pack(self.ctx.h, xv.h, C.c_void_p(plan.dev_send_idx.data_ptr()), ns, C.c_void_p(buf.data_ptr())), self.ctx.h)
         recv = self._view(out_ptr, max(nr, 1))[:nr]
         big = plan.n_loc >= self.overlap_min_rows
         self.n_exchanges += 1
@@ -403,6 +407,7 @@ class ShardedHierarchy:
             f = np.array([1.0 if flag else 0.0]); comm.allreduce_host(f, op="min"); return bool(f[0] > 0.5)
 
         ok = True
+        self._seg_args = []
         # the RCCL copy this process already uses (torch's); MGS_LIBRCCL overrides the path
         path = os.environ.get("MGS_LIBRCCL", os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")).encode()
         idbuf = C.create_string_buffer(128)
@@ -443,6 +448,44 @@ class ShardedHierarchy:
             ok = False; err = e
         if not agree(ok):
             return fail("plan hand-over", locals().get("err"))
+        # Pack-free exchanges: every rank reads the contiguous ranges it will send per peer from the library, ships their lengths,
+        # and installs what it will receive — collective, all levels or none (a rank that cannot keeps every rank on packed sends).
+        segs, ok = [], True
+        try:
+            for l, plan in enumerate(self.plans):
+                nseg = (C.c_int * comm.world)(); cap = sum(plan.send_counts) + comm.world + 1
+                lens = (C.c_int * cap)()
+                w = lib().mgs_hier_native_send_segments(self.h.h, l, nseg, lens, cap)
+                if w < 0:
+                    raise RuntimeError(f"mgs_hier_native_send_segments(level {l}) -> {w}")
+                out, k = [], 0
+                for p in range(comm.world):
+                    out.append(np.array(lens[k:k + nseg[p]], dtype=np.int64)); k += nseg[p]
+                segs.append(out)
+        except Exception as e:  # noqa: BLE001
+            ok = False; err = e
+        if agree(ok):
+            recv = [comm.exchange_lists(out) for out in segs]           # collective, level after level
+            try:
+                for l, r in enumerate(recv):
+                    nseg = np.ascontiguousarray([len(a) for a in r], dtype=np.int32)
+                    lens = np.ascontiguousarray(np.concatenate(r) if len(r) else np.zeros(0), dtype=np.int32)
+                    if lens.size == 0:
+                        lens = np.zeros(1, np.int32)
+                    self._seg_args.append((l, nseg, lens))
+            except Exception as e:  # noqa: BLE001
+                ok = False; err = e
+            if agree(ok):
+                for l, nseg, lens in self._seg_args:                    # every rank is here: the switch to ranges happens on all of them
+                    check(lib().mgs_hier_set_native_recv_segments(self.h.h, l, nseg.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p)), ctx.h)
+                self.native_segments = [[len(a) for a in out] for out in segs]
+                if log:
+                    log("native exchanges send contiguous row ranges straight from the vectors (ranges per peer and level: "
+                        + " ".join(str(x) for x in self.native_segments) + ")")
+            elif log:
+                log(f"native exchanges keep the pack kernel ({locals().get('err')!r})")
+        elif log:
+            log(f"native exchanges keep the pack kernel ({locals().get('err')!r})")
         # collective: one native halo exchange per level against the torch.distributed exchange, bit for bit
         for l, plan in enumerate(self.plans):
             try:
@@ -674,28 +717,36 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                              "mgs_comm_size": [cw.value, cr.value] if ncomm is not None else None,
                              "cycle_graph": graph_info, "generation": os.environ.get("MGS_BENCH_GEN_NAME"),
                              "exchanges_per_cycle_callbacks": None if sh.native else ex_per_cycle},
+               # a run that completed on a later generation of the launcher (slower transport) says so at top level
+               "degraded": bool(launch.abandoned_generations()), "abandoned_generations": launch.abandoned_generations(),
+               "multi_gpu_note": "the native RCCL transport with the cycle captured in one hipGraph has run on real links only where a scaling run of the "
+                                 "driver exists (see README / DESIGN.md §7); transport.generation names what this line was measured on",
                # whole-job rates of the sharded fine-level SpMV including its halo exchange: bytes that cross HBM (PMC traffic of the
                # full-grid launch) resp. the §8d-d3 CSR byte count, over the slowest rank's time
                "spmv_hbm_gbps": (tr[0] if tr else (streamed or loc_bytes) * n / n_loc) / (ms_x * 1e-3) / 1e9,
-               "spmv_algorithmic_gbps": spmv_bytes(n, nnz) / (ms_x * 1e-3) / 1e9,
-               "roofline": {"bound": "hbm", "achieved": g, "peak": 8000.0, "unit": "GB/s", "frac": g / 8000.0, "traffic": traffic,
+               "spmv_effective_csr_gbps": spmv_bytes(n, nnz) / (ms_x * 1e-3) / 1e9,
+               # roofline of the dominant kernel on rank 0's shard: bytes that cross HBM / launch time / 8 TB/s (PMC traffic of the committed
+               # full-grid profile scaled by this shard's rows — counters cannot be read inside a multi-process run; else the bytes the
+               # kernel streams by construction).  effective_csr_* = the SURVEY §8d-d3 CSR byte count over the same time.
+               "roofline": {"bound": "hbm", "achieved": (traffic or streamed or loc_bytes) / (ms_k * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                            "frac": (traffic or streamed or loc_bytes) / (ms_k * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
                             "traffic_source": (tr[1] + f" (full-grid launch, scaled by this shard's rows {n_loc}/{n})") if tr else None,
-                            "hbm_gbps": traffic / (ms_k * 1e-3) / 1e9 if traffic else None,
-                            "hbm_frac": traffic / (ms_k * 1e-3) / 1e9 / 8000.0 if traffic else None,
                             "kernel": "csr_rowblock_coded_kernel<SPMV> (rank 0 shard, per-GPU rate; CSR SpMV with pattern-coded column index)",
-                            "algorithmic_bytes_per_launch": loc_bytes, "ms_per_launch": ms_k, "ms_spmv_with_halo_exchange": ms_x,
+                            "ms_per_launch": ms_k, "ms_spmv_with_halo_exchange": ms_x,
+                            "effective_csr_bytes_per_launch": loc_bytes, "effective_csr_gbps": g, "effective_csr_frac": g / 8000.0,
                             "streamed_bytes_per_launch": streamed, "streamed_gbps": streamed / (ms_k * 1e-3) / 1e9 if streamed else None,
-                            "note": "achieved/frac = SURVEY §8d-d3 CSR bytes of the shard (12·nnz + 20·n + 4) / time: an EFFECTIVE rate — the coded kernel "
-                                    "streams 8 B per entry + 1 B per row (DESIGN.md §4), so hbm_gbps/hbm_frac (PMC traffic / time) is the physical HBM "
-                                    "rate; csr_kernel = plain 12 B/entry CSR kernel on the same shard",
+                            "note": "achieved/frac = bytes that cross HBM in one launch / launch time / 8 TB/s; effective_csr_* = SURVEY §8d-d3 CSR bytes of the "
+                                    "shard (12·nnz + 20·n + 4) / time — the coded kernel streams 8 B per entry + 1 B per row (DESIGN.md §4), so that figure "
+                                    "counts bytes that never move; csr_kernel = plain 12 B/entry CSR kernel on the same shard",
                             "csr_kernel": {"ms": ms_k_csr, "gbps": loc_bytes / (ms_k_csr * 1e-3) / 1e9},
                             "fused_pass_form": sh.h.fused_info(0)},
                "solve_check": {"bicgstab_status": st, "bicgstab_iterations": it, "bicgstab_tol": tol},
                "cpu_baseline": None}
     beat("teardown")
     comm.barrier()
-    if rank != 0:
-        launch.mark_done()           # this rank's part is complete: a crash while tearing RCCL down must not restart the generation
+    if rank == 0:
+        launch.persist_result(json.dumps(out))   # the finished measurement, before anything is torn down: the supervisor prints it if this worker dies
+    launch.mark_done()               # this rank's part is complete: a crash while tearing RCCL down must not restart the generation
     try:
         sh.close()
         del sh, b, x, xs, y, A
@@ -707,11 +758,16 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
         # CPU baseline on rank 0's host cores, after the other ranks are done (they do not wait for it)
         if cpu_baseline is not None:
             beat("cpu baseline")
+            wd_limit = getattr(wd, "limit", None)
+            if wd is not None:
+                wd.limit = max(wd.limit, 900.0)          # a full-size oracle sample: minutes of CPU work without a heartbeat
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # noqa: BLE001
                 log("cpu_baseline failed:", repr(e))
+            if wd is not None:
+                wd.limit = wd_limit
         (emit_json or (lambda o: print(json.dumps(o), flush=True)))(out)
-    launch.mark_done()
+        launch.mark_printed()
     if wd:
         wd.stop()

@@ -11,7 +11,12 @@ A worker is the same script with MGS_BENCH_WORKER=1.  Workers are started in GEN
 path next, host-staged gloo last.  A generation ends for everyone when a worker exits non-zero or its watchdog
 (`Watchdog`, no heartbeat for `MGS_BENCH_WATCHDOG_S` seconds → exit code 77) fires: a hang inside a collective that has
 never run on this machine costs one watchdog period instead of the whole run.  A worker that finished its part writes a
-marker file, so a crash during teardown does not restart anything.
+marker file, so a crash during teardown does not restart anything; rank 0 persists its JSON line in the run directory BEFORE it
+tears anything down, and its supervisor prints that file if the worker dies before printing it itself.  The change of generation
+is COLLECTIVE in both entry points: under torch.distributed.run the per-rank supervisors share the run directory, the one
+whose worker failed drops `fail.g<gen>` there, every supervisor polls for it, ends its own worker (exact pid) and all start
+generation g+1 together.  A run that completed in a later generation says so in its JSON line (`"degraded": true` and the
+reasons the earlier generations were abandoned for).
 
 Nothing here touches the GPU or imports torch.
 """
@@ -82,8 +87,16 @@ def _marker(rundir, gen, rank):
     return os.path.join(rundir, f"done.g{gen}.r{rank}")
 
 
+def _fail_file(rundir, gen):
+    return os.path.join(rundir, f"fail.g{gen}")
+
+
+def _result_file(rundir, gen):
+    return os.path.join(rundir, f"result.g{gen}.json")
+
+
 def mark_done():
-    """worker side: this rank's part of the generation is complete (the JSON line, if any, is out)"""
+    """worker side: this rank's part of the generation is complete (the JSON line, if any, is out or persisted)"""
     d = os.environ.get("MGS_BENCH_RUNDIR")
     if d:
         try:
@@ -91,6 +104,53 @@ def mark_done():
                 f.write("ok\n")
         except OSError:
             pass
+
+
+def persist_result(line):
+    """worker side (rank 0): the finished measurement, written before any teardown; the supervisor prints it if this worker
+    dies before it printed the line itself"""
+    d = os.environ.get("MGS_BENCH_RUNDIR")
+    if d:
+        try:
+            path = _result_file(d, os.environ.get("MGS_BENCH_GEN", "0"))
+            with open(path + ".tmp", "w") as f:
+                f.write(line)
+            os.replace(path + ".tmp", path)
+        except OSError:
+            pass
+
+
+def mark_printed():
+    """worker side (rank 0): the JSON line went out on stdout — nothing left for the supervisor to relay"""
+    d = os.environ.get("MGS_BENCH_RUNDIR")
+    if d:
+        try:
+            os.unlink(_result_file(d, os.environ.get("MGS_BENCH_GEN", "0")))
+        except OSError:
+            pass
+
+
+def _relay_unprinted(rundir, gen, out=None):
+    """supervisor side: rank 0's worker is gone; a result file still there was never printed"""
+    try:
+        path = _result_file(rundir, gen)
+        with open(path) as f:
+            line = f.read().strip()
+        os.unlink(path)
+    except OSError:
+        return False
+    if line:
+        (out or sys.stdout).write(line + "\n"); (out or sys.stdout).flush()
+    return bool(line)
+
+
+def abandoned_generations():
+    """worker side: [{generation, reason}] of the generations this run gave up before the current one (empty: first attempt)"""
+    import json
+    try:
+        return json.loads(os.environ.get("MGS_BENCH_ABANDONED", "[]"))
+    except ValueError:
+        return []
 
 
 def _worker_env(base, gen, rank, local_rank, world, addr, port, rundir):
@@ -122,12 +182,15 @@ def _kill(p):
 def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
     """`python bench.py --gpus N` without a launcher: N workers as child processes, generation after generation.
     Returns the exit code for the caller to exit with (0 = some generation completed on every rank)."""
+    import json
     rundir = tempfile.mkdtemp(prefix="mgs_bench_")
     limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "1500")) if total_timeout is None else total_timeout
     rc_final = 1
+    abandoned = []
     for gen in range(first_generation(), len(GENERATIONS)):
         port = free_port()
-        procs = [subprocess.Popen([sys.executable] + argv, env=_worker_env(os.environ, gen, r, r, world, "127.0.0.1", port, rundir))
+        base = dict(os.environ, MGS_BENCH_ABANDONED=json.dumps(abandoned))
+        procs = [subprocess.Popen([sys.executable] + argv, env=_worker_env(base, gen, r, r, world, "127.0.0.1", port, rundir))
                  for r in range(world)]
         log(f"generation {gen} ({GENERATIONS[gen][0]}): started {world} rank workers, rendezvous 127.0.0.1:{port}")
         t0, bad = time.monotonic(), None
@@ -135,6 +198,7 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
             codes = [p.poll() for p in procs]
             done = [c == 0 or (c is not None and os.path.exists(_marker(rundir, gen, r))) for r, c in enumerate(codes)]
             if all(done):
+                _relay_unprinted(rundir, gen)            # rank 0 finished its measurement but died before printing it
                 return 0
             failed = [r for r, c in enumerate(codes) if c is not None and not done[r]]
             if failed:
@@ -147,6 +211,7 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
         for p in procs:
             _kill(p)
         rc_final = next((c for c in (p.returncode for p in procs) if c not in (0, None)), 1)
+        abandoned.append({"generation": GENERATIONS[gen][0], "reason": bad})
         log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned: {bad}")
     return rc_final
 
@@ -154,34 +219,70 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
 def supervise_rank(argv, log=lambda *a: None):
     """one torch.distributed.run worker slot: start this rank's worker as a child, next generation on failure.
     Generation 0 meets on the launcher's own rendezvous (env://); later generations on MASTER_PORT + 1 + gen, hosted by
-    rank 0's worker, so nothing of an abandoned generation is reused."""
+    rank 0's worker, so nothing of an abandoned generation is reused.  The supervisors of one node share `rundir`: the one
+    whose worker fails writes fail.g<gen> (with the reason), all of them poll for it and leave the generation TOGETHER —
+    no rank waits in the rendezvous of generation g+1 while another still sits out its watchdog in generation g."""
+    import json
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     addr, port0 = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
     # the launcher agent is the common parent of the rank slots: its pid makes the directory unique to this run
     rundir = os.path.join(tempfile.gettempdir(), f"mgs_bench_{port0}_{os.getppid()}")
     os.makedirs(rundir, exist_ok=True)
-    for gen in range(len(GENERATIONS)):               # leftovers of an earlier run with the same pid and port
-        try:
-            os.unlink(_marker(rundir, gen, rank))
-        except OSError:
-            pass
+    for gen in range(len(GENERATIONS)):               # leftovers of an earlier run with the same pid and port (own files only:
+        for path in (_marker(rundir, gen, rank),):    # the shared fail/result files are keyed by generation and cleared by rank 0 below)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
     limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "1500"))
     rc = 1
     g0 = first_generation()
+    abandoned = []
     for gen in range(g0, len(GENERATIONS)):
-        env = _worker_env(os.environ, gen, rank, local_rank, world, addr, port0 if gen == g0 else port0 + 1 + gen, rundir)
+        base = dict(os.environ, MGS_BENCH_ABANDONED=json.dumps(abandoned))
+        env = _worker_env(base, gen, rank, local_rank, world, addr, port0 if gen == g0 else port0 + 1 + gen, rundir)
         if gen != g0:
             env["MGS_BENCH_OWN_STORE"] = "1"      # rank 0's worker hosts the TCPStore of this generation
         p = subprocess.Popen([sys.executable] + argv, env=env)
+        t0, reason = time.monotonic(), None
+        while True:
+            rc = p.poll()
+            if rc is not None:
+                if rc == 0 or os.path.exists(_marker(rundir, gen, rank)):
+                    if rank == 0:
+                        _relay_unprinted(rundir, gen)
+                    return 0
+                reason = f"rank {rank} worker exited with {rc}"
+                break
+            if os.path.exists(_fail_file(rundir, gen)):          # another rank's worker failed: leave this generation with it
+                try:
+                    reason = open(_fail_file(rundir, gen)).read().strip() or "another rank failed"
+                except OSError:
+                    reason = "another rank failed"
+                if os.path.exists(_marker(rundir, gen, rank)):   # this rank's part was complete already: nothing to redo here
+                    _kill(p)
+                    return 0
+                _kill(p); rc = EXIT_RETRY
+                break
+            if time.monotonic() - t0 > limit:
+                reason = f"rank {rank}: no completion within {limit:.0f}s"
+                _kill(p); rc = EXIT_RETRY
+                break
+            time.sleep(0.1)
+        if not os.path.exists(_fail_file(rundir, gen)):            # first to fail: tell the others (atomic create; losers keep the winner's reason)
+            try:
+                fd = os.open(_fail_file(rundir, gen), os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
+                os.write(fd, (reason or "failed").encode()); os.close(fd)
+            except OSError:
+                pass
         try:
-            rc = p.wait(timeout=limit)
-        except subprocess.TimeoutExpired:
-            _kill(p); rc = EXIT_RETRY
-        if rc == 0 or os.path.exists(_marker(rundir, gen, rank)):
-            return 0
+            reason = open(_fail_file(rundir, gen)).read().strip() or reason
+        except OSError:
+            pass
+        abandoned.append({"generation": GENERATIONS[gen][0], "reason": reason})
         if rank == 0:
-            log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned on rank 0 (worker exit {rc})")
+            log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned: {reason}")
     return rc
 
 

@@ -308,6 +308,7 @@ struct orc_hier {
   orc_dense_lu lu;
   double omega; int nu1, nu2;
   int kcycle_levels;
+  int kcycle_energy;   /* K-cycle coefficients from energy inner products (flexible CG form, SPD operators) instead of the GCR form */
   double corr_scale;   /* over-correction x += sigma * P e_c (0 or 1: the reference's form) */
   int additive;   /* bicg.cpp:59: multigrid_solve(v) + M2(v) instead of the multiplicative form */
   double **kc1, **kv1, **kc2, **kv2, **kr;
@@ -371,6 +372,7 @@ void orc_hier_destroy(orc_hier *h) {
 int orc_hier_nlev(const orc_hier *h) { return h->nlev; }
 void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2) { h->omega = omega; h->nu1 = nu1; h->nu2 = nu2; }
 void orc_hier_set_kcycle(orc_hier *h, int levels) { h->kcycle_levels = levels; }
+void orc_hier_set_kcycle_energy(orc_hier *h, int on) { h->kcycle_energy = on; }
 void orc_hier_set_additive(orc_hier *h, int on) { h->additive = on; }
 void orc_hier_set_correction_scale(orc_hier *h, double sigma) { h->corr_scale = sigma; }
 const orc_csr *orc_hier_A(const orc_hier *h, int l) { return &h->A[l]; }
@@ -397,12 +399,16 @@ static void coarse_solve_inner(const orc_hier *h, int l, const double *rhs, doub
   double *c1 = h->kc1[l], *v1 = h->kv1[l], *c2 = h->kc2[l], *v2 = h->kv2[l], *rp = h->kr[l];
   vcycle_rec(h, l, rhs, c1, 1);
   orc_spmv(A, c1, v1);
-  double rho1 = orc_dot(n, v1, v1), alpha1 = orc_dot(n, v1, rhs);
+  /* GCR form (paper §3.1, any operator): inner products with v = A c (minimal residual).  Energy form (flexible CG, SPD
+   * operators): the same five products with c in place of the left factor — ρ1 = c1·Ac1, α1 = c1·rhs, γ = c2·Ac1, β = c2·Ac2,
+   * α2 = c2·r' — i.e. the combination that minimises the A-norm of the error; the update formulas are the same. */
+  const double *d1 = h->kcycle_energy ? c1 : v1, *d2 = h->kcycle_energy ? c2 : v2;
+  double rho1 = orc_dot(n, d1, v1), alpha1 = orc_dot(n, d1, rhs);
   double a = rho1 != 0.0 ? alpha1 / rho1 : 0.0;
   for (int i = 0; i < n; i++) rp[i] = rhs[i] - a * v1[i];
   vcycle_rec(h, l, rp, c2, 1);
   orc_spmv(A, c2, v2);
-  double gamma = orc_dot(n, v2, v1), beta = orc_dot(n, v2, v2), alpha2 = orc_dot(n, v2, rp);
+  double gamma = orc_dot(n, d2, v1), beta = orc_dot(n, d2, v2), alpha2 = orc_dot(n, d2, rp);
   double k1 = 0.0, k2 = 0.0;
   if (rho1 != 0.0) {
     double rho2 = beta - gamma * gamma / rho1;

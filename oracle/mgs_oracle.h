@@ -85,6 +85,7 @@ void orc_hier_set_smoother(orc_hier *h, double omega, int nu1, int nu2);
 /* K-cycle on levels 1..levels (two GCR steps per coarse solve); 0 = V-cycle.  Derived from the
  * paper (docs/AGMG_For_Convection_Diffusion.pdf §3.1): no executable reference exists for it. */
 void orc_hier_set_kcycle(orc_hier *h, int levels);
+void orc_hier_set_kcycle_energy(orc_hier *h, int on);   /* K-cycle coefficients: 0 GCR form (default), 1 energy / flexible-CG form (SPD operators) */
 void orc_hier_set_additive(orc_hier *h, int on);   /* bicg.cpp:59 */
 void orc_hier_set_correction_scale(orc_hier *h, double sigma);   /* x += sigma * P e_c; derived knob, no reference counterpart */
 const orc_csr *orc_hier_A(const orc_hier *h, int l);

@@ -55,6 +55,7 @@ def lib():
         L.orc_hier_nlev.argtypes = [C.c_void_p]
         L.orc_hier_set_smoother.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]; L.orc_hier_set_smoother.restype = None
         L.orc_hier_set_kcycle.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_kcycle.restype = None
+        L.orc_hier_set_kcycle_energy.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_kcycle_energy.restype = None
         L.orc_hier_set_additive.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_set_additive.restype = None
         L.orc_hier_set_correction_scale.argtypes = [C.c_void_p, C.c_double]; L.orc_hier_set_correction_scale.restype = None
         L.orc_hier_A.argtypes = [C.c_void_p, C.c_int]; L.orc_hier_A.restype = cp
@@ -242,6 +243,11 @@ class Hier:
 
     def set_kcycle(self, levels):
         lib().orc_hier_set_kcycle(self.h, levels)
+        return self
+
+    def set_kcycle_energy(self, on=True):
+        """K-cycle coefficients from energy inner products (flexible-CG form, SPD operators) instead of the GCR form"""
+        lib().orc_hier_set_kcycle_energy(self.h, int(bool(on)))
         return self
 
     def set_correction_scale(self, sigma):

@@ -1,5 +1,5 @@
 """Stand-in for bench.py in tests/test_launch_cpu.py: same launch protocol (multigridsolver_amd/launch.py), no GPU.
-argv: <ok_from_generation> <mode: exit|hang|crash_after_done>.  A worker of an earlier generation fails the way `mode` says;
+argv: <ok_from_generation> <mode: exit|hang|crash_after_done|die_before_print>.  A worker of an earlier generation fails the way `mode` says;
 from generation `ok_from` on the ranks meet in a gloo process group, all-reduce their ranks and rank 0 prints one JSON line."""
 import json
 import os
@@ -34,8 +34,15 @@ def main():
     dist.all_reduce(t)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"generation": gen, "name": os.environ["MGS_BENCH_GEN_NAME"], "sum": float(t[0]), "world": dist.get_world_size(),
-                          "native": os.environ.get("MGS_NATIVE_RCCL"), "graph": os.environ.get("MGS_NATIVE_GRAPH")}), flush=True)
+        line = json.dumps({"generation": gen, "name": os.environ["MGS_BENCH_GEN_NAME"], "sum": float(t[0]), "world": dist.get_world_size(),
+                           "native": os.environ.get("MGS_NATIVE_RCCL"), "graph": os.environ.get("MGS_NATIVE_GRAPH"),
+                           "degraded": bool(launch.abandoned_generations()), "abandoned_generations": launch.abandoned_generations()})
+        launch.persist_result(line)        # before any teardown
+        launch.mark_done()
+        if mode == "die_before_print":
+            os._exit(9)                    # the measurement is finished and persisted: the supervisor prints it
+        print(line, flush=True)
+        launch.mark_printed()
     dist.destroy_process_group()
     launch.mark_done()
     wd.stop()

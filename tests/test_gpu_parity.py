@@ -786,6 +786,21 @@ def test_kcycle_vs_oracle(ctx, mg, orc):
     assert np.linalg.norm(Ao.residual(xg.numpy(), b_np)) / np.linalg.norm(b_np) <= 3e-10
     xi = ctx.vec(n); sti, iti, toli = mg.fgcr(A, xi, b, None, 10, 5000, 1e-8)    # unpreconditioned GCR(10)
     assert sti == 0 and iti > itg
+    # energy form of the K-cycle's coefficients (option kcycle_energy: flexible-CG inner products, SPD operators): same restatement in the oracle
+    ctx.set_option("kcycle_energy", 1); ho.set_kcycle_energy(1)
+    try:
+        for kl in (1, 2, 3):
+            h.set_kcycle(kl); ho.set_kcycle(kl)
+            xe, xo = h.vcycle(b).numpy(), ho.vcycle(b_np)
+            assert rel(xe, xo) <= 1e-9, kl
+        ho.set_kcycle_energy(0)
+        assert rel(xe, ho.vcycle(b_np)) > 1e-6, "the energy form did not change the K-cycle"
+        xe = ctx.vec(n); ste, ite, tole = mg.fgcr(A, xe, b, h, 10, 300, 1e-10)
+        # status 0 means the TRUE residual is below the tolerance (mgs_fgcr recomputes b − A·x before it says so)
+        assert ste == 0 and np.linalg.norm(Ao.residual(xe.numpy(), b_np)) / np.linalg.norm(b_np) <= 1.01e-10 and ite <= itg + 3
+    finally:
+        ctx.set_option("kcycle_energy", 0)
+    h.set_kcycle(0)
 
 
 def test_random_matrices_vs_oracle(ctx, mg, orc):

@@ -23,11 +23,14 @@ def _run(cmd, extra_env=None, timeout=300):
     return r, [json.loads(l) for l in lines]
 
 
-@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (2, "exit"), (1, "hang"), (0, "crash_after_done")])
+@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (2, "exit"), (1, "hang"), (0, "crash_after_done"), (0, "die_before_print")])
 def test_spawn_ranks_generations(ok_from, mode):
     r, out = _run([sys.executable, DUMMY, str(ok_from), mode, "2"], {"MGS_BENCH_WATCHDOG_S": "4"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert len(out) == 1 and out[0]["generation"] == ok_from and out[0]["sum"] == 1.0 and out[0]["world"] == 2, out
+    # a run that completed in a later generation says so, with the reason every earlier generation was abandoned for
+    assert out[0]["degraded"] == (ok_from > 0) and len(out[0]["abandoned_generations"]) == ok_from, out
+    assert all(a["reason"] for a in out[0]["abandoned_generations"])
     if ok_from == 0:
         assert out[0]["native"] == "1" and out[0]["graph"] == "1"
     if ok_from == 2:
@@ -39,7 +42,7 @@ def test_spawn_ranks_gives_up_with_the_workers_code():
     assert r.returncode != 0 and out == []
 
 
-@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (1, "exit"), (1, "hang")])
+@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (1, "exit"), (1, "hang"), (0, "die_before_print")])
 def test_supervisors_under_torchrun(ok_from, mode):
     port = 29300 + (os.getpid() % 500)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -47,6 +50,24 @@ def test_supervisors_under_torchrun(ok_from, mode):
     r, out = _run(cmd, {"MGS_BENCH_WATCHDOG_S": "4"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert len(out) == 1 and out[0]["generation"] == ok_from and out[0]["sum"] == 1.0, out
+    assert out[0]["degraded"] == (ok_from > 0) and len(out[0]["abandoned_generations"]) == ok_from, out
+
+
+def test_supervisors_change_generation_together():
+    """One rank's worker fails at once, the other hangs, and the watchdog is as long as in production (150 s): the supervisors
+    share the run directory, the hanging worker is ended the moment the failure is posted, and both ranks meet in the next
+    generation long before any watchdog would have fired — they cannot end up in different generations."""
+    import time
+    port = 29300 + ((os.getpid() + 250) % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           DUMMY, "1", "hang", "2"]
+    t0 = time.monotonic()
+    r, out = _run(cmd, {"MGS_BENCH_WATCHDOG_S": "150"}, timeout=140)
+    dt = time.monotonic() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(out) == 1 and out[0]["generation"] == 1 and out[0]["sum"] == 1.0, out
+    assert dt < 90, f"generation change waited for a watchdog ({dt:.0f} s)"
+    assert out[0]["abandoned_generations"][0]["generation"] == "native-rccl+graph" and "exited with" in out[0]["abandoned_generations"][0]["reason"]
 
 
 def test_first_generation_honours_explicit_choices():

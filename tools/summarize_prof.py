@@ -76,7 +76,38 @@ for k in [k for k in ["spmv", "residual", "jacobi", "fused_pre", "grouped_pre", 
                  "algorithmic_GBps_at_avg": ALG[k] / avg, "FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k],
                  "hbm_read_bytes_corrected": fb, "hbm_write_bytes_corrected": wb, "traffic_bytes": fb + wb,
                  "traffic_over_algorithmic": (fb + wb) / ALG[k], "fabric_GBps_at_avg": (fb + wb) / avg})
-summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
+
+
+def last_cycle(rows, name_key, grid_key):
+    """rows of the final V-cycle of the workload: from the last fine-level dispatch of the cycle's first kernel (grouped pre pass,
+    else the fused pre pass / residual on the fine level) to the end of the run"""
+    first = None
+    for i, r in enumerate(rows):
+        k = classify(r[name_key])
+        if k in ("grouped_pre", "fused_pre") and int(r[grid_key]) >= n // 8:
+            first = i
+    return rows[first:] if first is not None else []
+
+
+def cycle_counter(sub, counter):
+    rows = [r for r in csv.DictReader(open(newest(os.path.join(src, sub, "*", "*_counter_collection.csv")))) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    cyc = last_cycle(rows, "Kernel_Name", "Grid_Size")
+    return sum(float(r["Counter_Value"]) for r in cyc), len(cyc)
+
+
+trace.sort(key=lambda r: int(r["Dispatch_Id"]))
+cyc_t = last_cycle(trace, "Kernel_Name", "Grid_Size_X")
+cyc_fetch, nd_f = cycle_counter("pmc_fetch", "FETCH_SIZE")
+cyc_write, nd_w = cycle_counter("pmc_write", "WRITE_SIZE")
+vcycle = None
+if cyc_t and nd_f == len(cyc_t) and nd_w == len(cyc_t):
+    rd, wr = cyc_fetch * 1024 * cal_read, cyc_write * 1024 * cal_write
+    vcycle = {"dispatches": len(cyc_t), "kernel_ms": sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in cyc_t) / 1e6,
+              "wall_ms": (int(cyc_t[-1]["End_Timestamp"]) - int(cyc_t[0]["Start_Timestamp"])) / 1e6,
+              "hbm_read_bytes_corrected": rd, "hbm_write_bytes_corrected": wr, "traffic_bytes": rd + wr,
+              "note": "sum over every dispatch of the last V-cycle of the workload (eager launches), FETCH_SIZE/WRITE_SIZE passes corrected like the per-kernel rows"}
+summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "vcycle": vcycle, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
            "fetch_size_correction": cal_read, "write_size_correction": cal_write,
            "note": "FETCH_SIZE on gfx950 reports half the bytes of this access pattern (8-byte lanes): calibrated on axpby's known 16n read bytes; "
                    "counters come from L2's fabric-side requests, so Infinity-Cache hits are included (traffic >= HBM bytes). "
@@ -94,6 +125,10 @@ with open(os.path.join(REPO, "profiles", f"{tag}_summary.md"), "w") as f:
     for r in rows:
         f.write(f"| {r['kernel']} | {r['launches']} | {r['avg_us']:.1f} | {r['algorithmic_bytes'] / 1e9:.3f} | {r['algorithmic_GBps_at_avg']:.0f} | "
                 f"{r['traffic_bytes'] / 1e9:.3f} | {r['traffic_over_algorithmic']:.3f} | {r['fabric_GBps_at_avg']:.0f} |\n")
+    if vcycle:
+        f.write(f"\nOne V-cycle (last cycle of the workload, {vcycle['dispatches']} dispatches): kernel time {vcycle['kernel_ms']:.3f} ms, wall {vcycle['wall_ms']:.3f} ms, "
+                f"PMC traffic {vcycle['traffic_bytes'] / 1e9:.3f} GB (read {vcycle['hbm_read_bytes_corrected'] / 1e9:.3f} + write {vcycle['hbm_write_bytes_corrected'] / 1e9:.3f}) "
+                f"= {vcycle['traffic_bytes'] / vcycle['kernel_ms'] / 1e6:.0f} GB/s over its kernel time.\n")
     f.write("\n| kernel (whole workload incl. setup) | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in summary["top_kernels_by_total_time"]:
         f.write(f"| {r['name']} | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.1f} | {r['pct']:.2f} |\n")
