@@ -48,6 +48,14 @@ typedef struct mgs_xfer mgs_xfer; /* prolongation P with its restriction Pᵀ   
 typedef struct mgs_hier mgs_hier; /* multilevel hierarchy = the preconditioner state */
 
 /* ------------------------------------------------------------------ context */
+/* Device memory arena (optional; no reference counterpart).  One hipMalloc of `bytes` taken before the library's first device allocation;
+ * operators, vectors and setup scratch are then placed inside it (first fit from the low end, 2 MiB alignment for blocks of 1 MiB or more,
+ * coalescing on release) and requests that do not fit fall through to hipMalloc.  Same allocation sequence → same addresses in every
+ * process: the fine-level SpMV's process-to-process spread shrinks from ±3–4 % to ±1 %.  Environment MGS_ARENA_GB=N does
+ * the same at the first allocation; mgs_arena_reserve(0) rules an arena out.  mgs_arena_info: capacity, bytes in use, largest free block. */
+int mgs_arena_reserve(size_t bytes);
+int mgs_arena_info(size_t out[3]);
+
 /* device: HIP device ordinal.  stream: a hipStream_t to launch on (e.g. the caller's
  * torch stream) or NULL to let the context create its own.                          */
 int mgs_ctx_create(int device, void *stream, mgs_ctx **out);
@@ -181,6 +189,9 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
  * (default).  Scalars stay on the device.  On a row-sharded hierarchy the five inner products are summed over the
  * ranks (mgs_ctx_set_native_allreduce, else the mgs_ctx_set_allreduce callback); without either the level runs a V-cycle. */
 int mgs_hier_set_kcycle(mgs_hier *h, int levels);
+/* K iteration on level 0 itself when the hierarchy is applied from x = 0: for the replicated tail of a row-sharded hierarchy whose
+ * K-cycle reaches the last sharded level (that level is the tail's level 0; no rank reduction needed: the tail is replicated). */
+int mgs_hier_set_kcycle_entry(mgs_hier *h, int on);
 /* the additive switch of MultiGridPrecond::solve (reference src/common/bicg.cpp:59, `multiplicative_precond = false`; dead in the
  * reference — the constructor fixes it to true, :42): with on != 0 a zero-guess cycle returns, level by level,
  * P·cycle(Pᵀ v) + M2(v) with M2 = ωD⁻¹ instead of the multiplicative form.  The other switch, `use_preconditioner = false`
@@ -258,6 +269,10 @@ int mgs_hier_set_halo_exchange_fused(mgs_hier *h, mgs_halo_fused_fn fn, void *us
  * shard (n_coarse rows, n_coarse+n_halo_coarse local columns).  mgs_hier_push_level appends
  * the pair to a hierarchy and takes ownership of both.                                  */
 int mgs_aggregate_shard(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T);
+/* ... with zones (host array, one int per owned row; NULL = none): rows of different zones never share an aggregate.  Giving the rows each
+ * peer sees as halo a zone of their own keeps what that peer asks for at the next level a contiguous id range (plane shards), so every halo
+ * exchange of the hierarchy sends ranges straight from the vectors. */
+int mgs_aggregate_shard_zoned(const mgs_csr *A, double ktg, int npass, double tou, const int *zone, mgs_xfer **T);
 int mgs_galerkin_shard(const mgs_csr *A, const mgs_xfer *T, const int *halo_coarse_col,
                        int n_halo_coarse, mgs_csr **Ac);
 int mgs_hier_push_level(mgs_hier *h, mgs_xfer *T, mgs_csr *Ac);
@@ -317,6 +332,10 @@ int mgs_comm_destroy(mgs_comm *c);
 int mgs_comm_size(const mgs_comm *c, int *world, int *rank);
 int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int *send_idx, const int *send_counts, const int *recv_counts);
 int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs);
+/* Global tail row of every halo slot of the last sharded level (host array: first tail row of the owner rank + the owner's local
+ * row).  The replicated tail's solution holds the neighbours' entries too: the kernel that hands this rank its own slice then fills
+ * the level's halo slots from it, and the post pass of the level above needs no halo exchange for e_c.  n = 0 switches it off. */
+int mgs_hier_set_native_tail_halo(mgs_hier *h, const int *halo_global, int n);
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev);
 int mgs_hier_native_send_segments(const mgs_hier *h, int level, int *nseg_per_peer, int *seglens, int cap);
 int mgs_hier_set_native_recv_segments(mgs_hier *h, int level, const int *nseg_per_peer, const int *seglens);

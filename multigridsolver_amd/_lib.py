@@ -44,7 +44,10 @@ PROTOTYPES = {
     "mgs_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgs_hier_set_native_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_set_native_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_hier_set_native_tail_halo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mgs_hier_native_halo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mgs_arena_reserve": (C.c_int, [C.c_size_t]),
+    "mgs_arena_info": (C.c_int, [C.c_void_p]),
     "mgs_hier_native_send_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "mgs_hier_set_native_recv_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mgs_ctx_set_native_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -90,6 +93,7 @@ PROTOTYPES = {
     "mgs_hier_finalize": (C.c_int, [C.c_void_p]),
     "mgs_hier_set_smoother": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     "mgs_hier_set_kcycle": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgs_hier_set_kcycle_entry": (C.c_int, [C.c_void_p, C.c_int]),
     "mgs_hier_set_additive": (C.c_int, [C.c_void_p, C.c_int]),
     "mgs_hier_set_correction_scale": (C.c_int, [C.c_void_p, C.c_double]),
     "mgs_hier_destroy": (C.c_int, [C.c_void_p]),
@@ -104,6 +108,7 @@ PROTOTYPES = {
     "mgs_halo_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mgs_hier_set_halo_exchange": (C.c_int, [C.c_void_p, HALO_FN, C.c_void_p]),
     "mgs_aggregate_shard": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
+    "mgs_aggregate_shard_zoned": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mgs_galerkin_shard": (C.c_int, [C.c_void_p, C.c_void_p, c_int_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mgs_hier_push_level": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_xfer_from_agg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.POINTER(C.c_void_p)]),

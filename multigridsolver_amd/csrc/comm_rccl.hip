@@ -19,7 +19,7 @@ struct mgs_comm {
   void *dl = nullptr;
   ncclComm_t comm = nullptr;
   int world = 0, rank = 0;
-  bool capturable = true;     // false: host-synchronous stand-in (tests/fake_rccl exports mgs_fake_rccl_marker)
+  bool capturable = true;     // false: host-synchronous stand-in (tests/fake_rccl exports mgs_fake_rccl_marker = 1; = 2: its stream-ordered mode, capturable)
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
@@ -50,7 +50,8 @@ static int load_api(mgs_ctx *ctx, const char *librccl, mgs_comm *c) {
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
   SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-  c->capturable = dlsym(c->dl, "mgs_fake_rccl_marker") == nullptr;
+  const int *marker = reinterpret_cast<const int *>(dlsym(c->dl, "mgs_fake_rccl_marker"));     // tests/fake_rccl: 1 = host-synchronous calls, 2 = stream-ordered
+  c->capturable = !marker || *marker == 2;
   return MGS_OK;
 }
 bool mgs_comm_capturable(const mgs_comm *c) { return c && c->capturable; }

@@ -135,6 +135,37 @@ __global__ void restrict_agg_kernel(int nc, const int *__restrict__ cptr, const 
   for (int k = k0 + 4; k < e; ++k) s += r[members[k]];
   rc[c] = s;
 }
+// Small levels (launch-bound, a few µs per dispatch whatever they do): the zero-guess pre pass r = b − Â·b and the restriction
+// r_c = Pᵀr in ONE kernel, aggregate-parallel — four lanes per aggregate, lane q walks the row of member q (plain CSR of Â, ascending
+// columns, unfused multiply/add from 0.0: the row-block kernel's arithmetic), stores r for the post pass, and lane 0 adds the members'
+// residuals in ascending member order (restrict_agg_kernel's order): same bits as the two kernels it replaces, one dispatch less per
+// level.  Rows outside every aggregate (G0) get their residual from the tail of the grid.  hv: halo payload of a row shard (NULL: none).
+__global__ __launch_bounds__(TB) void agg_pre_kernel(int n, int nc, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                      const double *__restrict__ valhat, const double *__restrict__ b, const double *__restrict__ hv,
+                                                      const int *__restrict__ cptr, const int *__restrict__ members, const int *__restrict__ agg,
+                                                      double *__restrict__ r_out, double *__restrict__ rc_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  auto row_residual = [&](int m) -> double {
+    double s = 0.0;
+    for (int e = rowptr[m], ee = rowptr[m + 1]; e < ee; ++e) { const int c = col[e]; s += valhat[e] * (c < n ? b[c] : hv[c - n]); }
+    return b[m] - s;
+  };
+  const int a = t >> 2, q = t & 3;
+  if (a < nc) {                                   // the four lanes of a group share a: same trip counts, converged shuffles
+    const int k0 = cptr[a], ke = cptr[a + 1];
+    double acc = 0.0;
+    for (int kb = k0; kb < ke; kb += 4) {         // one round for the aggregates of the pairwise passes (≤ 4 members)
+      double rm = 0.0;
+      if (kb + q < ke) { const int m = members[kb + q]; rm = row_residual(m); r_out[m] = rm; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const double v = __shfl(rm, j, 4); if (kb + j < ke) acc += v; }
+    }
+    if (q == 0) rc_out[a] = acc;
+  } else {
+    const int row = t - 4 * nc;
+    if (row < n && agg[row] < 0) r_out[row] = row_residual(row);
+  }
+}
 // e = P e_c / x += P e_c: `P * (...)`, reference bicg.cpp:48; P has ≤1 unit entry per row
 // (src/CPU_C++/AGMG.cpp:181-186) so e_i = e_c[agg(i)] or 0 for G0 rows.
 template <int ADD>
@@ -552,6 +583,14 @@ int k_diag_pos(const mgs_csr *A, unsigned char *dpos) {
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
+int k_agg_pre(const mgs_csr *A, const double *valhat, const double *b, const double *hv, const mgs_xfer *T, double *r_out, double *rc_out) {
+  mgs_ctx *ctx = A->ctx;
+  const int64_t threads = 4 * (int64_t)T->n_coarse + (T->nnz < (int64_t)A->rows ? A->rows : 0);   // rows outside every aggregate only where there are any
+  if (threads) hipLaunchKernelGGL(agg_pre_kernel, dim3(mgs_grid(threads, TB)), dim3(TB), 0, ctx->stream, A->rows, T->n_coarse, A->rowptr, A->col, valhat, b, hv,
+                                  T->cptr, T->members, T->agg, r_out, rc_out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc) {
   if (nc) hipLaunchKernelGGL(restrict_agg_kernel, dim3(mgs_grid(nc, TB)), dim3(TB), 0, ctx->stream, nc, cptr, members, r, rc);
   MGS_HIP(ctx, hipGetLastError());
@@ -615,6 +654,18 @@ int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out) 
 }
 int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *cmap, int *out) {
   if (A->rows) hipLaunchKernelGGL(map_cols_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, cmap, out);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+// last sharded level: own slice of the replicated tail's solution, and the level's halo slots from the same vector (it holds the
+// neighbours' entries too) — what the copy of the slice plus a halo exchange would deliver, in one dispatch and without the wire
+__global__ void tail_scatter_kernel(const double *__restrict__ xt, int my_off, int n_loc, const int *__restrict__ halo_global, int n_halo, double *__restrict__ x) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_loc) x[j] = xt[my_off + j];
+  else if (j < n_loc + n_halo) x[j] = xt[halo_global[j - n_loc]];
+}
+int k_tail_scatter(mgs_ctx *ctx, const double *xt, int my_off, int n_loc, const int *halo_global, int n_halo, double *x) {
+  if (n_loc + n_halo) hipLaunchKernelGGL(tail_scatter_kernel, dim3(mgs_grid(n_loc + n_halo, TB)), dim3(TB), 0, ctx->stream, xt, my_off, n_loc, halo_global, n_halo, x);
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

@@ -81,7 +81,9 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // 7-point stencil): instead of plane after plane, a strip of S row blocks is followed through all
 // planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
 // p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
-struct BlockMap { int nblocks, chunk, remap, D, S, P, base, gap_at = 0x7fffffff, gap_len = 0; };   // base: first row block of the launched range;
+struct BlockMap { int nblocks, chunk, remap, D, S, P, base, gap_at = 0x7fffffff, gap_len = 0;
+                  unsigned mps = 0, mS = 0; };   // ⌊2³²/(P·S)⌋+1 and ⌊2³²/S⌋+1: quotients by multiply-high (0: divide) — set by finish_map
+// base: first row block of the launched range;
 // row blocks >= gap_at are shifted by gap_len (one launch over the leading + trailing boundary blocks of a row shard)
 __device__ __forceinline__ int block_of(const BlockMap &m, int vb) { const int b = m.base + vb; return b >= m.gap_at ? b + m.gap_len : b; }
 __device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx);
@@ -92,9 +94,11 @@ __device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
 __device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx) {
   int lb = idx;
   if (m.D > 0) {
+    // (the two integer divisions of this map compiled to ~70 dependent scalar instructions at the head of EVERY wave, in front of its first
+    //  load: a quotient by multiply-high is two.  Exact for idx·divisor < 2³², which finish_map checks on the host.)
     const int ps = m.P * m.S;
-    const int s = idx / ps, rem = idx - s * ps;
-    const int p = rem / m.S, t = rem - p * m.S;
+    const int s = m.mps ? (int)__umulhi((unsigned)idx, m.mps) : idx / ps, rem = idx - s * ps;
+    const int p = m.mS ? (int)__umulhi((unsigned)rem, m.mS) : rem / m.S, t = rem - p * m.S;
     const int off = s * m.S + t;
     if (off >= m.D) return -1;
     lb = p * m.D + off;
@@ -1391,6 +1395,15 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 }
 
 
+// multiply-high constants of a strip-major map (see map_block_xi); grid_x = workgroups of the launch
+static void finish_map(const mgs_ctx *ctx, BlockMap &bm, unsigned grid_x) {
+  bm.mps = bm.mS = 0;
+  if (!ctx->opt_mapmul || bm.D <= 0 || bm.S <= 0 || bm.P <= 0) return;
+  const unsigned long long ps = (unsigned long long)bm.P * (unsigned long long)bm.S, nmax = grid_x / 8 + 1;
+  if (nmax * ps >= (1ull << 32) || ps * (unsigned long long)bm.S >= (1ull << 32)) return;     // quotient not exact by this method: divide
+  bm.mps = (unsigned)((1ull << 32) / ps) + 1u;
+  bm.mS = (unsigned)((1ull << 32) / (unsigned long long)bm.S) + 1u;
+}
 // workgroup → group map: XCD-contiguous, strip-major for far bands (distances in groups instead of row blocks)
 static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) {
   mgs_ctx *ctx = A->ctx;
@@ -1408,7 +1421,9 @@ static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) 
       per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
     }
   }
-  return dim3(bm.remap ? per_xcd * 8 : bm.nblocks);
+  const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  finish_map(ctx, bm, grid.x);
+  return grid;
 }
 
 void mgs_free_groups(mgs_groups *g) {
@@ -1604,7 +1619,9 @@ static dim3 plan_block_map(const mgs_csr *A, int blk_lo, int blk_hi, BlockMap &b
       per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
     }
   }
-  return dim3(bm.remap ? per_xcd * 8 : bm.nblocks);
+  const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  finish_map(ctx, bm, grid.x);
+  return grid;
 }
 
 // The coded kernel on the row blocks [blk_lo, blk_hi) of the view A (A->col = the coded index array, A->code its
@@ -1651,6 +1668,7 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
     }
   }
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  finish_map(ctx, bm, grid.x);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
   if (which == FUSE_POST_MAPPED && use_rowcode(A, A->code))      // A is the view whose col/code are the aggregate-mapped ones
@@ -1732,6 +1750,7 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
     return MGS_OK;
   }
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
+  finish_map(ctx, bm, grid.x);
   if (ctx->opt_spmv_variant == 0 && !ctx->opt_nontemporal && use_rowcode(A, A->code))
     return launch_coded(A, A->code, op, A->col, x, b, dinv, omega, nullptr, nullptr, out, grid, bm);
   size_t lds = sizeof(double) * (size_t)(cap > 0 ? cap : 1);

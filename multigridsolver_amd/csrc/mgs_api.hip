@@ -7,6 +7,95 @@
 
 thread_local std::string g_mgs_last_error;
 
+// ------------------------------------------------------------------ device memory arena (see mgs_internal.hpp)
+#undef hipMalloc
+#undef hipFree
+#include <map>
+#include <mutex>
+namespace {
+struct Arena {
+  char *base = nullptr; size_t cap = 0; bool tried = false;
+  std::map<size_t, size_t> free_blocks;     // offset → size, address ordered
+  std::map<size_t, size_t> used;            // offset → size
+  std::mutex m;
+} g_arena;
+bool arena_take_locked(size_t cap) {
+  void *p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+  g_arena.base = (char *)p; g_arena.cap = cap; g_arena.free_blocks[0] = cap;
+  return true;
+}
+void arena_init_locked() {
+  if (g_arena.tried) return;
+  g_arena.tried = true;
+  const char *e = getenv("MGS_ARENA_GB");
+  const double gb = e ? atof(e) : 0.0;
+  if (gb <= 0.0) return;
+  if (!arena_take_locked((size_t)(gb * 1024.0) << 20)) fprintf(stderr, "[mgs] arena of %.1f GiB not available: plain hipMalloc\n", gb);
+}
+}  // namespace
+// One arena per process, reserved before the library's first device allocation (else MGS_ARENA_GB decides at that allocation).
+extern "C" int mgs_arena_reserve(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_arena.m);
+  if (g_arena.base) return mgs_fail(nullptr, MGS_ERR_STATE, "mgs_arena_reserve: an arena of %zu bytes exists already", g_arena.cap);
+  g_arena.tried = true;
+  if (bytes == 0) return MGS_OK;                                   // explicit "no arena", whatever the environment says
+  if (!arena_take_locked(bytes)) return mgs_fail(nullptr, MGS_ERR_ALLOC, "mgs_arena_reserve: hipMalloc(%zu bytes) failed", bytes);
+  return MGS_OK;
+}
+extern "C" int mgs_arena_info(size_t out[3]) {                     // capacity, bytes in use, largest free block
+  std::lock_guard<std::mutex> lk(g_arena.m);
+  size_t used = 0, big = 0;
+  for (auto &u : g_arena.used) used += u.second;
+  for (auto &f : g_arena.free_blocks) big = std::max(big, f.second);
+  out[0] = g_arena.cap; out[1] = used; out[2] = big;
+  return MGS_OK;
+}
+hipError_t mgs_hip_malloc(void **p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_arena.m);
+    arena_init_locked();
+    if (g_arena.base) {
+      const size_t align = bytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : (size_t)4096;
+      const size_t need = (std::max(bytes, (size_t)1) + align - 1) / align * align;
+      for (auto it = g_arena.free_blocks.begin(); it != g_arena.free_blocks.end(); ++it) {
+        const size_t off = (it->first + align - 1) / align * align, pad = off - it->first;
+        if (it->second < pad + need) continue;
+        const size_t bo = it->first, bs = it->second;
+        g_arena.free_blocks.erase(it);
+        if (pad) g_arena.free_blocks[bo] = pad;
+        if (bs > pad + need) g_arena.free_blocks[off + need] = bs - pad - need;
+        g_arena.used[off] = need;
+        *p = g_arena.base + off;
+        return hipSuccess;
+      }
+    }
+  }
+  return hipMalloc(p, bytes);
+}
+hipError_t mgs_hip_free(void *p) {
+  if (!p) return hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(g_arena.m);
+    if (g_arena.base && (char *)p >= g_arena.base && (char *)p < g_arena.base + g_arena.cap) {
+      const size_t off = (size_t)((char *)p - g_arena.base);
+      auto u = g_arena.used.find(off);
+      if (u == g_arena.used.end()) return hipErrorInvalidValue;
+      size_t bo = off, bs = u->second;
+      g_arena.used.erase(u);
+      (void)hipDeviceSynchronize();                       // hipFree's contract: nothing in flight touches the block afterwards
+      auto nx = g_arena.free_blocks.lower_bound(bo);
+      if (nx != g_arena.free_blocks.end() && nx->first == bo + bs) { bs += nx->second; nx = g_arena.free_blocks.erase(nx); }
+      if (nx != g_arena.free_blocks.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == bo) { bo = pv->first; bs += pv->second; g_arena.free_blocks.erase(pv); } }
+      g_arena.free_blocks[bo] = bs;
+      return hipSuccess;
+    }
+  }
+  return hipFree(p);
+}
+#define hipMalloc(p, n) mgs_hip_malloc((void **)(p), (n))
+#define hipFree(p) mgs_hip_free((void *)(p))
+
 int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...) {
   char buf[1024];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -172,6 +261,8 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "blas1_pairs") ctx->opt_blas1_pairs = value;
   else if (k == "stage_unroll") ctx->opt_stage_unroll = value;
   else if (k == "kcycle_energy") ctx->opt_kcycle_energy = value;
+  else if (k == "aggpre_max_rows") ctx->opt_aggpre_max_rows = value;
+  else if (k == "mapmul") ctx->opt_mapmul = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;
@@ -463,7 +554,7 @@ int mgs_hier_create(mgs_ctx *ctx, const mgs_csr *A, double omega, int nu1, int n
 static void free_native_tail(mgs_hier *h) {
   mgs_native_tail *T = h->ntail;
   if (!T) return;
-  if (T->send) hipFree(T->send); if (T->all) hipFree(T->all); if (T->gidx) hipFree(T->gidx);
+  if (T->send) hipFree(T->send); if (T->all) hipFree(T->all); if (T->gidx) hipFree(T->gidx); if (T->halo_global) hipFree(T->halo_global);
   mgs_vec_destroy(T->b); mgs_vec_destroy(T->x);
   delete T; h->ntail = nullptr;
 }
@@ -562,6 +653,7 @@ int mgs_hier_set_native_recv_segments(mgs_hier *h, int level, const int *nseg, c
 }
 int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int *nlocs) {
   mgs_ctx *ctx = h->ctx;
+  hipStreamSynchronize(ctx->stream);
   free_native_tail(h);
   drop_graph(h);
   if (!c || !tail) return MGS_OK;
@@ -587,6 +679,26 @@ int mgs_hier_set_native_tail(mgs_hier *h, mgs_comm *c, mgs_hier *tail, const int
   if (rc != MGS_OK) return fail(rc);
   return MGS_OK;
 }
+// Global tail row of every halo slot of the LAST sharded level (host array, one int per slot: first row of the owner in the tail's
+// numbering + the owner's local row).  The replicated tail's solution holds the neighbours' entries too, so the kernel that hands this
+// rank its own slice also fills the level's halo slots from it: the post pass of the level above needs no halo exchange for e_c
+// (one exchange less per cycle, same values and the same bits as the exchange would deliver).  n = 0 switches it off.
+int mgs_hier_set_native_tail_halo(mgs_hier *h, const int *halo_global, int n) {
+  mgs_ctx *ctx = h->ctx;
+  MGS_CHECK(ctx, h->ntail, MGS_ERR_STATE, "mgs_hier_set_native_tail_halo: install the native tail first");
+  mgs_native_tail *T = h->ntail;
+  hipStreamSynchronize(ctx->stream);
+  drop_graph(h);
+  if (T->halo_global) { hipFree(T->halo_global); T->halo_global = nullptr; T->n_halo_global = 0; }
+  if (n <= 0 || !halo_global) return MGS_OK;
+  const mgs_csr *Al = h->lev.back().A;
+  MGS_CHECK(ctx, n == Al->cols - Al->rows, MGS_ERR_INVALID, "mgs_hier_set_native_tail_halo: %d rows given, the last sharded level has %d halo slots", n, Al->cols - Al->rows);
+  for (int k = 0; k < n; ++k) MGS_CHECK(ctx, halo_global[k] >= 0 && halo_global[k] < T->n_t, MGS_ERR_INVALID, "mgs_hier_set_native_tail_halo: slot %d maps to row %d outside the tail (%d rows)", k, halo_global[k], T->n_t);
+  MGS_TRY(mgs_dev_alloc(ctx, &T->halo_global, (size_t)n));
+  MGS_HIP(ctx, hipMemcpy(T->halo_global, halo_global, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  T->n_halo_global = n;
+  return MGS_OK;
+}
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev) {
   MGS_CHECK(h->ctx, level >= 0 && level < (int)h->lev.size() && h->lev[level].nx, MGS_ERR_STATE, "mgs_hier_native_halo: level %d has no native plan", level);
   return native_exchange(h, level, (const double *)x_dev, (double *)x_dev + h->lev[level].A->rows);
@@ -597,6 +709,7 @@ int mgs_hier_set_kcycle(mgs_hier *h, int levels) {
   h->kcycle_levels = levels; drop_graph(h);
   return MGS_OK;
 }
+int mgs_hier_set_kcycle_entry(mgs_hier *h, int on) { h->kcycle_entry = on != 0; drop_graph(h); return MGS_OK; }
 int mgs_hier_set_correction_scale(mgs_hier *h, double sigma) {
   MGS_CHECK(h->ctx, sigma > 0.0 && sigma <= 4.0, MGS_ERR_INVALID, "mgs_hier_set_correction_scale: sigma must lie in (0, 4]");
   h->corr_scale = sigma; drop_graph(h);
@@ -644,11 +757,23 @@ int mgs_hier_push_P(mgs_hier *h, const mgs_csr *P) {
   return push_level(h, T, Ac);
 }
 
-int mgs_aggregate_shard(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T) {
+int mgs_aggregate_shard(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T) { return mgs_aggregate_shard_zoned(A, ktg, npass, tou, nullptr, T); }
+// zone (host, one int per owned row; NULL: none): rows of different zones never share an aggregate.  The host side gives the rows a peer
+// sees as halo a zone of their own: the aggregates that peer will ask for at the next level are then exactly the aggregates of those
+// rows — a contiguous id range on plane shards, level after level — and every halo exchange sends ranges straight from the vectors.
+int mgs_aggregate_shard_zoned(const mgs_csr *A, double ktg, int npass, double tou, const int *zone, mgs_xfer **T) {
+  mgs_ctx *ctx = A->ctx;
   mgs_csr *Ac = nullptr;
-  MGS_TRY(k_pairwise_aggregate(A, ktg, npass, tou, T, &Ac));
+  int *dz = nullptr;
+  if (zone && A->rows) {
+    MGS_TRY(mgs_dev_alloc(ctx, &dz, (size_t)A->rows));
+    if (hipMemcpy(dz, zone, sizeof(int) * (size_t)A->rows, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dz); return mgs_fail(ctx, MGS_ERR_HIP, "mgs_aggregate_shard_zoned: upload failed"); }
+  }
+  const int rc = k_pairwise_aggregate(A, ktg, npass, tou, T, &Ac, dz);
+  hipStreamSynchronize(ctx->stream);
+  if (dz) hipFree(dz);
   if (Ac) mgs_csr_destroy(Ac);
-  return MGS_OK;
+  return rc;
 }
 int mgs_galerkin_shard(const mgs_csr *A, const mgs_xfer *T, const int *halo_coarse_col, int n_halo_coarse, mgs_csr **Ac) {
   mgs_ctx *ctx = A->ctx;
@@ -816,7 +941,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 static bool kcycle_here(const mgs_hier *h, int l) {
   const bool sharded = h->halo || h->halo_begin || h->native;
   // row shards: the five inner products are summed over the ranks — needs a reduction transport (native RCCL or the callback)
-  return l >= 1 && l <= h->kcycle_levels && l < (int)h->lev.size() - 1 && h->lev[l].kscal &&
+  return (l >= 1 ? l <= h->kcycle_levels : h->kcycle_entry) && l < (int)h->lev.size() - 1 && h->lev[l].kscal &&
          (!sharded || h->ctx->ncomm || h->ctx->allreduce);
 }
 // sum of `cnt` device scalars over the ranks of a row-sharded run (no-op on one GPU)
@@ -837,7 +962,11 @@ static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x);
 // coarse vector (n_c entries), so every form of the level above — fused, grouped, unfused, K-cycle — sees σ·e_c
 static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
   MGS_TRY(coarse_solve_inner(h, l, rhs, x));
-  if (h->corr_scale != 1.0) MGS_TRY(k_axpby(h->ctx, h->lev[l].n, h->corr_scale, x, 0.0, x));
+  if (h->corr_scale != 1.0) {
+    // (the last sharded level's halo slots were filled from the replicated tail's solution together with the owned entries: scale them as well)
+    const bool tail_halo = h->ntail && h->ntail->halo_global && l == (int)h->lev.size() - 1 && x == h->lev[l].x->d;
+    MGS_TRY(k_axpby(h->ctx, tail_halo ? h->lev[l].n_ext : h->lev[l].n, h->corr_scale, x, 0.0, x));
+  }
   return MGS_OK;
 }
 static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x) {
@@ -880,9 +1009,12 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
         MGS_TRY(mgs_comm_allgather(T->comm, T->send, T->all, (size_t)std::max(T->maxn, 1)));
         MGS_TRY(k_gather(ctx, T->all, T->gidx, T->n_t, T->b->d));
       }
-      if (h->capturing) MGS_TRY(cycle_level(T->tail, 0, tb, T->x->d, true));   // part of the outer graph (prepare_fused ran before the capture)
+      if (h->capturing) MGS_TRY(coarse_solve_inner(T->tail, 0, tb, T->x->d));   // part of the outer graph (prepare_fused ran before the capture); K iteration at the entry level if asked for
       else { mgs_vec bv; bv.ctx = ctx; bv.n = T->n_t; bv.d = const_cast<double *>(tb); bv.owns = false; MGS_TRY(mgs_vcycle(T->tail, &bv, T->x, 1)); }
-      if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(x, T->x->d + T->my_off, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
+      // own slice back; with the global rows of this level's halo slots known (mgs_hier_set_native_tail_halo) the same kernel fills the halo
+      // slots from the replicated solution — the level above then needs no exchange for e_c
+      if (T->halo_global && x == L.x->d) MGS_TRY(k_tail_scatter(ctx, T->x->d, T->my_off, T->n_loc, T->halo_global, T->n_halo_global, x));
+      else if (T->n_loc) MGS_HIP(ctx, hipMemcpyAsync(x, T->x->d + T->my_off, sizeof(double) * (size_t)T->n_loc, hipMemcpyDeviceToDevice, ctx->stream));
       return MGS_OK;
     }
     if (h->coarse) { int rc = h->coarse(h->coarse_user, b, x); return rc ? mgs_fail(ctx, MGS_ERR_STATE, "coarse solver callback failed (%d)", rc) : MGS_OK; }
@@ -951,6 +1083,12 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
       if (!split) return launch(0, nb, 0x7fffffff, 0);
       return launch(0, lo + nb - hi, lo, hi - lo);   // leading + trailing boundary blocks, one launch
     };
+    auto exchange_now = [&](int q, const double *src, double *dst) -> int {      // exchange, nothing launched meanwhile
+      if (h->lev[q].nx) return native_exchange(h, q, src, dst);
+      int rc = h->halo_fused(h->halo_user, q, 2, src, nullptr, dst, 0);
+      if (!rc) rc = h->halo_fused(h->halo_user, q, 2, src, nullptr, dst, 1);
+      return rc ? mgs_fail(ctx, MGS_ERR_STATE, "halo exchange of the fused passes failed at level %d (%d)", q, rc) : MGS_OK;
+    };
     // Setup-time operands: Â = A·diag(wd) makes the pre pass the plain residual kernel with x = b (one gather per
     // entry); A·P (or col_agg = the coarse column of every entry) lets the post pass gather e_c directly.  On a shard the
     // halo columns of Â read the payload buffer (the pattern-coded kernel knows that split); those of A·P read e_c's own halo.
@@ -964,9 +1102,12 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
                           (!halo || mgs_rowcode_usable(&Ahat, true));
     const int *cmap = L.cmap_ext ? L.cmap_ext : L.T->agg;        // gather forms: coarse column of every local column
     double *ec = C.x->d, *ec_halo = C.x->d + C.n;
+    // e_c's halo: one exchange on the coarse level's plan — unless that level is the replicated tail's, whose solution already holds the
+    // neighbours' entries (the kernel that hands over the own slice fills the halo slots too)
+    const bool ec_exchange = chalo && !(l + 2 == (int)h->lev.size() && h->ntail && h->ntail->halo_global);
     // post pass on the operand (A·P / aggregate-mapped A): the pattern-coded kernel where the code serves it, the gather kernel otherwise
     auto post_operand = [&](const double *bvec, const double *xin) -> int {
-      return pass_with_exchange(chalo, l + 1, ec, ec_halo, [&](int b0, int b1, int ga, int gl) {
+      return pass_with_exchange(ec_exchange, l + 1, ec, ec_halo, [&](int b0, int b1, int ga, int gl) {
         return mgs_launch_fused_range(&Amap, FUSE_POST_MAPPED, L.wd->d, bvec, xin, L.T->agg, ec, x, nullptr, nullptr, b0, b1, ga, gl); });
     };
     // Grouped form: pre pass + restriction in one kernel (r stays in LDS; L.r receives t = b + r, L.tmp the residuals of the
@@ -975,18 +1116,20 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     const bool grouped = ctx->opt_fuse_restrict && operands && L.grp && !(Ahat.code && Ahat.code->vtab) &&
                          (!halo || L.nx || !split || (h->capturing));
     if (grouped) {
-      if (halo) {
-        if (L.nx) MGS_TRY(native_exchange(h, l, b, L.hbuf->d));
-        else {
-          int rc = h->halo_fused(h->halo_user, l, 2, b, nullptr, L.hbuf->d, 0);
-          if (!rc) rc = h->halo_fused(h->halo_user, l, 2, b, nullptr, L.hbuf->d, 1);
-          if (rc) return mgs_fail(ctx, MGS_ERR_STATE, "halo exchange of the fused passes failed at level %d (%d)", l, rc);
-        }
-      }
+      if (halo) MGS_TRY(exchange_now(l, b, L.hbuf->d));
       MGS_TRY(mgs_launch_group_pre(&Ahat, L.grp, L.T, b, b, L.r->d, L.tmp->d, C.b->d, hv, L.A->rows));
       MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
       if (ctx->opt_group_sweep & 1) Amap.sweep = L.grp;
       return post_operand(L.r->d, nullptr);
+    }
+    // small level (a dispatch costs what it costs, whatever it does): pre pass and restriction in one aggregate-parallel kernel
+    if (ctx->opt_fuse_operands && L.val_wd && L.A->rows <= ctx->opt_aggpre_max_rows && L.A->max_row_len <= 64) {
+      if (halo) MGS_TRY(exchange_now(l, b, L.hbuf->d));
+      MGS_TRY(k_agg_pre(L.A, L.val_wd, b, hv, L.T, L.r->d, C.b->d));
+      MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
+      if (operands) return post_operand(L.r->d, b);
+      return pass_with_exchange(ec_exchange, l + 1, ec, ec_halo, [&](int b0, int b1, int ga, int gl) {
+        return mgs_launch_fused_range(L.A, FUSE_POST, L.wd->d, L.r->d, b, cmap, ec, x, nullptr, nullptr, b0, b1, ga, gl); });
     }
     // r = b − A·x1 with x1 = wd∘b (never stored: the POST pass recomputes it from b)
     if (operands && halo)
@@ -1000,7 +1143,7 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
     MGS_TRY(coarse_solve(h, l + 1, C.b->d, C.x->d));
     // x = x1 + Pe + wd∘(r − A·Pe)
     if (operands) return post_operand(L.r->d, b);
-    return pass_with_exchange(chalo, l + 1, ec, ec_halo, [&](int b0, int b1, int ga, int gl) {
+    return pass_with_exchange(ec_exchange, l + 1, ec, ec_halo, [&](int b0, int b1, int ga, int gl) {
       return mgs_launch_fused_range(L.A, FUSE_POST, L.wd->d, L.r->d, b, cmap, ec, x, nullptr, nullptr, b0, b1, ga, gl); });
   }
   // number of out-of-place sweeps decides where the ping-pong ends; start so that it ends in x
@@ -1053,7 +1196,7 @@ static int prepare_fused(mgs_hier *h) {
   if (ctx->opt_rowcode)      // pattern codes of the level operators (a cache attached to the matrices)
     for (mgs_level &L : h->lev)
       if (!L.A->code_tried) { MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(L.A))); drop_graph(h); }
-  for (int l = 1; l <= h->kcycle_levels && l < (int)h->lev.size() - 1; ++l) {
+  for (int l = h->kcycle_entry ? 0 : 1; l <= h->kcycle_levels && l < (int)h->lev.size() - 1; ++l) {
     mgs_level &L = h->lev[l];
     if (L.kscal) continue;
     for (mgs_vec **q : {&L.kc1, &L.kv1, &L.kc2, &L.kv2, &L.kr}) MGS_TRY(mgs_vec_create(ctx, L.n_ext, q));
@@ -1078,7 +1221,8 @@ static int prepare_fused(mgs_hier *h) {
     }
     if (shard && !L.cmap_ext && L.T->halo_cmap && L.T->n_halo_fine == L.A->cols - L.A->rows) {      // coarse column of every local column
       MGS_TRY(mgs_dev_alloc(ctx, &L.cmap_ext, (size_t)L.A->cols));
-      MGS_TRY(k_concat_i32(ctx, L.T->agg, L.A->rows, L.T->halo_cmap, L.T->n_halo_fine, L.cmap_ext)); drop_graph(h);
+      MGS_TRY(k_concat_i32(ctx, L.T->agg, L.A->rows, L.T->halo_cmap, L.T->n_halo_fine, L.cmap_ext));
+      drop_graph(h);
     }
     if (shard && !L.cmap_ext) continue;      // shard not built by mgs_galerkin_shard: one kernel per step on this level
     const bool rescale = L.wd_omega != h->omega;
@@ -1131,6 +1275,9 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   MGS_CHECK(ctx, b->d != x->d, MGS_ERR_INVALID, "mgs_vcycle: x must not alias b");
   MGS_CHECK(ctx, !h->additive || zero_guess, MGS_ERR_INVALID, "mgs_vcycle: the additive form (bicg.cpp:59) is a preconditioner application from x = 0 only");
   if (h->lev.size() == 1 && !h->coarse_sweeps) return cycle_level(h, 0, b->d, x->d, true);
+  auto entry = [&](const double *bb, double *xx, bool zg) -> int {      // kcycle_entry: two Krylov steps on level 0 itself (zero guess only)
+    return (h->kcycle_entry && zg) ? coarse_solve_inner(h, 0, bb, xx) : cycle_level(h, 0, bb, xx, zg);
+  };
   // sharded level 0 needs halo room behind the owned entries: work in the level's own buffer
   double *xw = x->d;
   const bool staged = x->n < L0.n_ext;
@@ -1150,7 +1297,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   if (h->graph_epoch != ctx->opt_epoch) drop_graph(h);
   h->graph_epoch = ctx->opt_epoch;
   if (!use_graph) {
-    MGS_TRY(cycle_level(h, 0, b->d, xw, zero_guess != 0));
+    MGS_TRY(entry(b->d, xw, zero_guess != 0));
   } else {
     const int zg = zero_guess != 0;
     mgs_hier::GraphSlot *slot = nullptr, *victim = &h->graphs[0];
@@ -1168,7 +1315,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
       hipGraph_t g = nullptr;
       MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       h->capturing = true;
-      int rc = cycle_level(h, 0, b->d, xw, zg != 0);
+      int rc = entry(b->d, xw, zg != 0);
       h->capturing = false;
       hipError_t e = hipStreamEndCapture(ctx->stream, &g);
       if (e == hipSuccess && rc == MGS_OK) {
@@ -1182,7 +1329,7 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
         (void)hipGetLastError();
         h->native_graph_failed = true;
         ctx->err = std::string("native cycle not captured (") + (rc != MGS_OK ? ctx->err.c_str() : hipGetErrorString(e)) + "): eager launches";
-        MGS_TRY(cycle_level(h, 0, b->d, xw, zg != 0));
+        MGS_TRY(entry(b->d, xw, zg != 0));
         if (staged) MGS_HIP(ctx, hipMemcpyAsync(x->d, xw, sizeof(double) * (size_t)L0.n, hipMemcpyDeviceToDevice, ctx->stream));
         return MGS_OK;
       }

@@ -59,6 +59,8 @@ struct mgs_ctx {
   int opt_stage_unroll = 1;   // row-block kernels stage their value slice without a loop in front of the barrier (predicated 16-byte loads / LDS-DMA): −4 … −7 % per cycle
   int opt_blas1_pairs = 1;    // ... pairs per lane of those kernels: 1 = one-shot workgroups (0: capped persistent grid, k: k pairs per lane)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
+  int opt_aggpre_max_rows = 100000;   // levels with at most this many rows run pre pass + restriction as ONE aggregate-parallel kernel (launch-bound sizes; same bits)
+  int opt_mapmul = 1;    // strip-major block map: quotients by multiply-high instead of two integer divisions at the head of every wave
   int opt_kcycle_energy = 0;  // K-cycle coefficients from energy inner products (flexible-CG form; SPD operators) instead of the GCR form of the paper
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:
@@ -166,6 +168,8 @@ struct mgs_native_tail {
   double *send = nullptr, *all = nullptr;   // maxn / world·maxn doubles
   int *gidx = nullptr;              // n_t: position of global tail row i in `all`
   mgs_vec *b = nullptr, *x = nullptr;
+  int *halo_global = nullptr;       // device: global tail row of every halo slot of the last sharded level (mgs_hier_set_native_tail_halo)
+  int n_halo_global = 0;
 };
 
 // Aggregate-complete row-block groups of a level (kernels_spmv.hip, "grouped pre pass"): one workgroup sweeps the 1–2 row
@@ -217,6 +221,8 @@ struct mgs_hier {
   int nu1 = 1, nu2 = 1;
   bool finalized = false;
   int kcycle_levels = 0;   // levels 1..kcycle_levels solve their coarse problem with 2 GCR steps (K-cycle)
+  bool kcycle_entry = false;   // ... and so does level 0 when the hierarchy is entered from x = 0 (replicated tail of a row-sharded hierarchy whose
+                               // K-cycle reaches the last sharded level: that level IS the tail's level 0)
   double corr_scale = 1.0; // over-correction: x ← x + σ·P e_c (σ = 1: the reference's form, bicg.cpp:48)
   bool additive = false;   // bicg.cpp:59: multigrid_solve(v) + M2(v) instead of the multiplicative form (M2 = ωD⁻¹)
   // coarsest direct solve
@@ -246,6 +252,16 @@ struct mgs_hier {
   std::vector<hipEvent_t> fork_events;   // fork/join events of the captured native cycle (two per overlapped exchange)
   size_t fork_used = 0;
 };
+
+// ------------------------------------------------------------------ device memory arena (mgs_api.hip)
+// Every device allocation of the library goes through these two.  With an arena (MGS_ARENA_GB = N, or mgs_arena_reserve) the library takes
+// ONE hipMalloc of N GiB at its first allocation and places operators and vectors inside it (first fit, lowest address first, 2 MiB
+// alignment for anything of 1 MiB or more, blocks coalesced on release); requests that do not fit fall through to hipMalloc.  Without
+// one (default) they are hipMalloc / hipFree.  Why: DESIGN.md §5 "process to process".
+hipError_t mgs_hip_malloc(void **p, size_t bytes);
+hipError_t mgs_hip_free(void *p);
+#define hipMalloc(p, n) mgs_hip_malloc((void **)(p), (n))
+#define hipFree(p) mgs_hip_free((void *)(p))
 
 // ------------------------------------------------------------------ error plumbing
 extern thread_local std::string g_mgs_last_error;
@@ -288,6 +304,7 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
 int k_scale_vals(mgs_ctx *ctx, const mgs_csr *A, const double *wd, double *out);            // out_k = a_k·wd[col_k] (row shards: wd covers the halo columns too)
 int k_map_cols(mgs_ctx *ctx, const mgs_csr *A, const int *cmap, int *out);                     // out_k = cmap[col_k]
 int k_concat_i32(mgs_ctx *ctx, const int *a, int na, const int *b, int nb, int *out);
+int k_tail_scatter(mgs_ctx *ctx, const double *xt, int my_off, int n_loc, const int *halo_global, int n_halo, double *x);   // x[0..n_loc) = xt[my_off..], x[n_loc+s] = xt[halo_global[s]]
 int mgs_plan_csr(mgs_csr *A);
 int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, const int *base, int split, mgs_rowcode **out,
                       const double *val = nullptr);
@@ -306,6 +323,7 @@ int mgs_launch_group_pre(const mgs_csr *Ahat, const mgs_groups *G, const mgs_xfe
 int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host);
 int k_diag_pos(const mgs_csr *A, unsigned char *dpos);
 int k_restrict_agg(mgs_ctx *ctx, int nc, const int *cptr, const int *members, const double *r, double *rc);
+int k_agg_pre(const mgs_csr *A, const double *valhat, const double *b, const double *hv, const mgs_xfer *T, double *r_out, double *rc_out);   // small levels: pre pass + restriction, one dispatch
 int k_prolong_agg(mgs_ctx *ctx, int n, const int *agg, const double *ec, double *x, int add);
 int k_fill(mgs_ctx *ctx, double *d, int64_t n, double v);
 int k_rand(mgs_ctx *ctx, double *d, int64_t n, uint64_t seed, int64_t off);
@@ -336,7 +354,7 @@ int k_build_ap(const mgs_csr *A, const mgs_xfer *T, const int *cmap_ext, int nco
 int k_galerkin_agg_ext(const mgs_csr *A, const mgs_xfer *T, const int *halo_map_dev, int n_halo_c, mgs_csr **out);
 int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_host, mgs_xfer **out);
 int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out);
-int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out);
+int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out, const int *zone_dev = nullptr);
 
 // helpers (mgs_api.hip)
 int mgs_csr_alloc(mgs_ctx *ctx, int rows, int cols, int64_t nnz, mgs_csr **out);

@@ -259,15 +259,16 @@ __global__ void agg_node_stats_kernel(int n, const int *__restrict__ rowptr, con
 // μ≤0 or μ>ktg (AGMG.cpp:163,171).
 __global__ void agg_edge_weight_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
                                        const double *__restrict__ diag, const double *__restrict__ s, const int *__restrict__ state,
-                                       double ktg, double *__restrict__ w) {
+                                       double ktg, const int *__restrict__ zone /*NULL: none; rows of different zones never pair*/, double *__restrict__ w) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double aii = diag[i], si = s[i];
   const bool gi = state[i] == -2;
+  const int zi = zone ? zone[i] : 0;
   for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
     int j = col[k]; double aij = val[k];
     double wk = INFINITY;
-    if (j != i && j < n && aij != 0.0 && !gi && state[j] != -2) {
+    if (j != i && j < n && aij != 0.0 && !gi && state[j] != -2 && (!zone || zone[j] == zi)) {
       double ajj = diag[j], sj = s[j];
       if (aii - si + ajj - sj >= 0) {
         double aji = csr_lookup(rowptr, col, val, j, i);
@@ -351,6 +352,11 @@ __global__ void agg_origin_kernel(int n, const int *__restrict__ agg, const int 
   if (i >= n) return;
   const int a = agg[i];
   if (a >= 0) atomicMin(&corigin[a], origin ? origin[i] : i);
+}
+// zone of an aggregate = zone of its members (rows of different zones never pair, so they agree)
+__global__ void agg_zone_kernel(int n, const int *__restrict__ agg, const int *__restrict__ zone, int *__restrict__ czone) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && agg[i] >= 0) czone[agg[i]] = zone[i];
 }
 __global__ void agg_compose_kernel(int n, int *__restrict__ agg, const int *__restrict__ agg2) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,7 +587,7 @@ int k_galerkin_general(const mgs_csr *A, const mgs_xfer *T, mgs_csr **out) {
 }
 
 // one pairwise pass on matrix M → agg ids (device array, caller frees) and count
-static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, const int *origin, int **agg_out, int *nc_out) {
+static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, const int *origin, const int *zone, int **agg_out, int *nc_out) {
   mgs_ctx *ctx = M->ctx;
   const int n = M->rows;
   DevBuf diag, s, state, w, pick, cnt, flag, asym;
@@ -600,7 +606,7 @@ static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, const int
   if (hasym) MGS_TRY(k_transpose(M, &Mt));
   hipLaunchKernelGGL(agg_node_stats_kernel, g, b, 0, st, n, M->rowptr, M->col, M->val, Mt ? Mt->rowptr : nullptr, Mt ? Mt->col : nullptr,
                      Mt ? Mt->val : nullptr, ktg, first_pass, diag.as<double>(), s.as<double>(), state.as<int>());
-  hipLaunchKernelGGL(agg_edge_weight_kernel, g, b, 0, st, n, M->rowptr, M->col, M->val, diag.as<double>(), s.as<double>(), state.as<int>(), ktg, w.as<double>());
+  hipLaunchKernelGGL(agg_edge_weight_kernel, g, b, 0, st, n, M->rowptr, M->col, M->val, diag.as<double>(), s.as<double>(), state.as<int>(), ktg, zone, w.as<double>());
   MGS_HIP(ctx, hipGetLastError());
   const int MAX_ROUNDS = 96, MU_ROUNDS = 24;
   for (int round = 0; round < MAX_ROUNDS; ++round) {
@@ -629,13 +635,13 @@ static int pairwise_pass(const mgs_csr *M, double ktg, int first_pass, const int
 }
 
 // multiple pairwise aggregation, AGMG.cpp:299-315 / main.cu:95-277
-int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out) {
+int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mgs_xfer **T_out, mgs_csr **Ac_out, const int *zone) {
   mgs_ctx *ctx = A->ctx;
   MGS_CHECK(ctx, A->rows <= A->cols && A->rows > 0, MGS_ERR_INVALID, "aggregate: need a non-empty operator with rows <= cols");
   MGS_CHECK(ctx, ktg > 2.0 && npass >= 1, MGS_ERR_INVALID, "aggregate: need ktg > 2 and npass >= 1");
   const int n = A->rows;
   int *agg = nullptr; int nc = 0;
-  MGS_TRY(pairwise_pass(A, ktg, 1, A->origin, &agg, &nc));
+  MGS_TRY(pairwise_pass(A, ktg, 1, A->origin, zone, &agg, &nc));
   mgs_xfer *T = nullptr;
   MGS_TRY(xfer_from_agg(ctx, n, nc, agg, &T));
   auto origin_of = [&](int nfine, const int *aggv, const int *org_fine, int ncoarse, int **out) -> int {
@@ -654,7 +660,14 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     if (Abar->rows <= 1) break;
     const int n_halo = A->cols - A->rows;                               // row shard: halo slots stay unaggregated here
     int *agg2 = nullptr; int nc2 = 0;
-    rc = pairwise_pass(Abar, ktg, 0, T->corigin, &agg2, &nc2);
+    DevBuf czone;                                                         // zones of the pairs (row shards: exported rows pair among themselves only)
+    if (zone) {
+      rc = dalloc<int>(ctx, czone, (size_t)std::max(Abar->rows, 1));
+      if (rc != MGS_OK) break;
+      hipMemsetAsync(czone.p, 0, sizeof(int) * (size_t)std::max(Abar->rows, 1), ctx->stream);
+      hipLaunchKernelGGL(agg_zone_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, T->agg, zone, czone.as<int>());
+    }
+    rc = pairwise_pass(Abar, ktg, 0, T->corigin, zone ? czone.as<int>() : nullptr, &agg2, &nc2);
     if (rc != MGS_OK) break;
     int *org2 = nullptr;
     rc = origin_of(Abar->rows, agg2, T->corigin, nc2, &org2);

@@ -109,7 +109,7 @@ def shard_from_global(n, rowptr, col, val, world, rank, exchange_lists):
     return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data, n_loc + len(halo_glob), plan
 
 
-def coarse_plan_handshake(plan, agg_loc, nc_loc, exchange_lists):
+def coarse_plan_handshake(plan, agg_loc, nc_loc, exchange_lists, span_slack=2.5):
     """One setup handshake per level (host arrays only).
     agg_loc: aggregate id of every owned row (−1 = none).  exchange_lists(list_per_peer) →
     list_per_peer is the variable-size all-to-all of int arrays.
@@ -117,12 +117,23 @@ def coarse_plan_handshake(plan, agg_loc, nc_loc, exchange_lists):
     world = len(plan.send_idx)
     # a. tell every peer the aggregate of the rows it sees as halo
     ragg = exchange_lists([agg_loc[idx].astype(np.int64) for idx in plan.send_idx])
-    # b. distinct remote aggregates per peer → coarse halo slots (grouped by peer, ascending id)
+    # b. distinct remote aggregates per peer → coarse halo slots (grouped by peer, ascending id).  Where the distinct ids nearly fill
+    #    their span (plane shards: the aggregates of a boundary plane are a prefix of the peer's ids, or interleave with those of the
+    #    plane behind it) the slots cover the whole span: the peer then sends ONE contiguous range of its vector, straight from memory
+    #    (no pack kernel), for at most `span_slack` times the bytes; the extra slots are halo columns no matrix entry refers to.
     halo_cols, uniq, off = [], [], 0
     for p in range(world):
         r = np.asarray(ragg[p], dtype=np.int64)
         assert len(r) == len(plan.recv_ids[p]), "halo handshake: peer sent a wrong-sized list"
         u = np.unique(r[r >= 0])
+        if len(u) and span_slack > 1.0:
+            # clusters of ids (a gap wider than the whole list is never worth filling: both boundary planes of a peer that is this rank's
+            # upper AND lower neighbour — two ranks, or the one-GPU rehearsal — stay two ranges); each cluster is filled if that costs little
+            cuts = np.nonzero(np.diff(u) > len(u))[0] + 1
+            parts = []
+            for c in np.split(u, cuts):
+                parts.append(np.arange(c[0], c[-1] + 1, dtype=np.int64) if (c[-1] - c[0] + 1) <= span_slack * len(c) else c)
+            u = np.concatenate(parts)
         cols = np.full(len(r), -1, dtype=np.int32)
         ok = r >= 0
         cols[ok] = nc_loc + off + np.searchsorted(u, r[ok])
@@ -134,6 +145,19 @@ def coarse_plan_handshake(plan, agg_loc, nc_loc, exchange_lists):
         assert a.size == 0 or (a.min() >= 0 and a.max() < nc_loc), "peer requested an aggregate this rank does not own"
     hc = np.concatenate(halo_cols) if halo_cols else np.zeros(0, np.int32)
     return hc.astype(np.int32), off, coarse
+
+
+def export_zones(plan):
+    """zone id of every owned row for mgs_aggregate_shard_zoned: 0 = interior; the rows sent to peer p get a zone of their own per
+    contiguous run of that peer's list (a row sent to several peers keeps the zone of the last one: still never paired with the interior)"""
+    zone = np.zeros(plan.n_loc, dtype=np.int32)
+    for p, idx in enumerate(plan.send_idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size == 0:
+            continue
+        run = np.concatenate([[0], np.cumsum(np.diff(idx) != 1)])
+        zone[idx] = 1 + 16 * p + np.minimum(run, 15)
+    return zone
 
 
 def shard_to_global(plan, rowptr, col, val, offsets, rank):
@@ -351,8 +375,10 @@ class ShardedHierarchy:
         self._pending[("f", level)] = self.comm.a2a_f64(recv, buf[:ns], plan.recv_counts, plan.send_counts, async_op=big)
 
     # ---- setup
-    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=2500, max_levels=32, log=None, overlap=True, fused=True, native=None):
+    def build(self, ktg=10.0, npass=2, tou=8.0, tail_rows=600_000, coarse_rows=2500, max_levels=32, log=None, overlap=True, fused=True, native=None, zoned=None):
         comm, ctx = self.comm, self.ctx
+        if zoned is None:
+            zoned = os.environ.get("MGS_SHARD_ZONES", "1") != "0"
         self._prepare_plan(0)
         A = self.A
         while True:
@@ -361,9 +387,28 @@ class ShardedHierarchy:
             if n_glob <= tail_rows or len(self.plans) >= max_levels:
                 break
             T = C.c_void_p()
-            check(lib().mgs_aggregate_shard(A.h, ktg, npass, tou, C.byref(T)), ctx.h)
+            # zones: the rows a peer sees as halo pair among themselves only (one zone per peer and contiguous run of its list), so that peer's
+            # requests at the next level are exactly their aggregates — a contiguous id range on plane shards, level after level
+            zone = export_zones(plan) if zoned else None
+            check(lib().mgs_aggregate_shard_zoned(A.h, ktg, npass, tou, zone.ctypes.data_as(C.c_void_p) if zone is not None else None, C.byref(T)), ctx.h)
             xf = core.Xfer(ctx, T, owned=True)
             agg = xf.agg(); nc_loc = xf.shape[1]
+            if zone is not None and np.any(zone):
+                # Zones pay while the exported rows still coarsen among themselves (plane shards: in-plane boxes, ÷4 per level).  Where the
+                # operator's strong couplings point out of the exported layer (deeper levels: z), its rows stay singletons, the layer stops
+                # shrinking and the coarse levels grow: this level is then aggregated without zones (its successor's lists go through the
+                # pack kernel again; those levels are small).  A local decision: peers only ever see aggregate ids.
+                ex = agg[zone > 0]
+                n_ex, n_exc = int(ex.size), int(np.unique(ex[ex >= 0]).size) + int(np.count_nonzero(ex < 0))
+                if n_exc * 2 > n_ex:
+                    del xf
+                    T = C.c_void_p()
+                    check(lib().mgs_aggregate_shard_zoned(A.h, ktg, npass, tou, None, C.byref(T)), ctx.h)
+                    xf = core.Xfer(ctx, T, owned=True)
+                    agg = xf.agg(); nc_loc = xf.shape[1]
+                    zoned = False              # deeper levels stall as well
+                    if log:
+                        log(f"level {len(self.plans) - 1}: exported rows do not coarsen among themselves ({n_ex} -> {n_exc}): aggregated without zones from here on")
             ncs = comm.allgather_ints(nc_loc)
             if int(ncs.sum()) > 0.9 * n_glob or int(ncs.min()) == 0:   # stalled somewhere: stop sharding here
                 del xf
@@ -444,6 +489,11 @@ class ShardedHierarchy:
                 check(lib().mgs_hier_set_native_exchange(self.h.h, l, c, ip(idx) if idx.size else None, ip(sc), ip(rc)), ctx.h)
             nl = np.ascontiguousarray(self.tail_nlocs, dtype=np.int32)
             check(lib().mgs_hier_set_native_tail(self.h.h, c, self.tail.h, nl.ctypes.data_as(C.c_void_p)), ctx.h)
+            # global tail row of every halo slot of the last sharded level: the level above reads e_c straight from the tail's solution
+            lp = self.plans[-1]
+            if lp.n_halo and os.environ.get("MGS_TAIL_ALIAS", "1") != "0":
+                hg = np.concatenate([self.tail_offs[p] + ids.astype(np.int64) for p, ids in enumerate(lp.recv_ids)]).astype(np.int32)
+                check(lib().mgs_hier_set_native_tail_halo(self.h.h, hg.ctypes.data_as(C.c_void_p), int(hg.size)), ctx.h)
         except Exception as e:  # noqa: BLE001
             ok = False; err = e
         if not agree(ok):
@@ -587,7 +637,9 @@ class ShardedHierarchy:
         self.install_allreduce()
         self.h.set_kcycle(levels)
         if self.tail:
-            self.tail.set_kcycle(max(0, levels - (len(self.plans) - 1)))
+            L = len(self.plans) - 1                    # the last sharded level is the tail's level 0
+            self.tail.set_kcycle(max(0, levels - L))
+            check(lib().mgs_hier_set_kcycle_entry(self.tail.h, 1 if (L >= 1 and levels >= L) else 0), self.ctx.h)
         return self
 
     def vcycle(self, b, x, zero_guess=True):

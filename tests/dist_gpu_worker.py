@@ -57,6 +57,24 @@ def main():
     b = ctx.vec(bg[lo * n2: hi * n2]); x = ctx.vec(n_ext)
     sh.vcycle(b, x)
     x_loc = x.numpy(n_loc)
+    graph = None
+    if os.environ.get("MGS_FAKE_RCCL_STREAM") == "1" and sh.native:
+        # stream-ordered stand-in: the native cycle is CAPTURED (after two eager runs) with its exchanges, tail all-gather and tail cycle
+        # inside the graph, and replayed — same bits as the eager cycle, on every rank
+        for _ in range(4):
+            sh.vcycle(b, x)
+        ctx.sync()
+        graph = sh.h.graph_info()
+        assert graph["captured_cycles"] >= 1 and not graph["native_capture_failed"] and graph["native_eager_runs"] == 2, graph
+        assert np.array_equal(x.numpy(n_loc), x_loc), "replayed cycle differs from the eager cycle"
+        # a second (rhs, out) pair takes another slot of the graph cache; more pairs than slots evict the oldest (replayed results stay right)
+        outs = [ctx.vec(n_ext) for _ in range(5)]
+        for rep in range(2):
+            for o in outs:
+                sh.vcycle(b, o)
+        ctx.sync()
+        for o in outs:
+            assert np.array_equal(o.numpy(n_loc), x_loc), "cycle replayed from an evicted / re-captured slot differs"
     if fused and not mtx and N >= 40 and not os.environ.get("MGS_OPTIONS"):
         # the shard runs the fused passes on their setup-time operands with pattern-coded, halo-tagged indices
         fi = sh.h.fused_info(0)
@@ -112,6 +130,13 @@ def main():
         kerr = np.linalg.norm(xk.numpy(n_loc) - xkr[lo * n2: hi * n2]) / np.linalg.norm(xkr[lo * n2: hi * n2])
         assert kerr <= 1e-9, kerr
         assert np.linalg.norm(xk.numpy(n_loc) - x_loc) > 1e-6 * np.linalg.norm(x_loc), "K-cycle did not change the cycle"
+        # K levels reaching past the last sharded level: that level (the replicated tail's entry level) gets its two Krylov steps too
+        kdeep = len(sh.plans) + 1
+        sh.set_kcycle(kdeep); ho.set_kcycle(kdeep)
+        xk2 = ctx.vec(n_ext); sh.vcycle(b, xk2)
+        xk2r = ho.vcycle(bg)
+        kerr2 = np.linalg.norm(xk2.numpy(n_loc) - xk2r[lo * n2: hi * n2]) / np.linalg.norm(xk2r[lo * n2: hi * n2])
+        assert kerr2 <= 1e-9, ("K-cycle through the replicated tail", kerr2)
         sh.set_kcycle(0); ho.set_kcycle(0)
     # preconditioned solve across shards (dots all-reduced), true residual checked globally
     xsol = ctx.vec(n_ext)
@@ -125,7 +150,7 @@ def main():
     dist.barrier()
     if rank == 0:
         ngrp = sum(1 for l in range(len(sh.plans) - 1) if sh.h.group_info(l)["groups"] > 0)
-        print(f"DIST_OK world={world} N={N} grouped_levels={ngrp} sharded_levels={len(sh.plans)} total_levels={sh.nlev} kcycle_err={kerr} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
+        print(f"DIST_OK world={world} N={N} graph={graph} grouped_levels={ngrp} sharded_levels={len(sh.plans)} total_levels={sh.nlev} kcycle_err={kerr} vcycle_err={err:.2e} bicgstab_it={it} res={res:.2e} exchanges={sh.n_exchanges}")
     del sh, b, x, xs, y, xsol, A
     ctx.close()
     dist.destroy_process_group()

@@ -17,13 +17,18 @@
 #include <thread>
 #include <vector>
 
-// tells libmgs that these entry points are host-synchronous (never captured into a hipGraph)
+// tells libmgs what these entry points are: 1 = host-synchronous (never captured into a hipGraph); 2 = STREAM-ORDERED
+// (MGS_FAKE_RCCL_STREAM=1): every transfer is a device→pinned copy, a host function that moves the bytes through the files, and a
+// pinned→device copy, all enqueued on the caller's stream — so the calls can be captured into a hipGraph and replayed like RCCL's
+// kernels, and the captured multi-rank cycle (exchanges, tail all-gather, all-reduced K-cycle scalars) runs on one GPU.
 extern "C" int mgs_fake_rccl_marker = 1;
+namespace { struct ModeInit { ModeInit() { const char *e = getenv("MGS_FAKE_RCCL_STREAM"); if (e && e[0] == '1') mgs_fake_rccl_marker = 2; } } g_mode_init; }
 
 struct ncclComm {
   std::string dir;
   int world = 0, rank = 0;
   std::vector<unsigned long long> sent, recvd;   // per peer sequence numbers
+  char *arena = nullptr; size_t arena_cap = 0, arena_used = 0;   // stream-ordered mode: pinned staging, bump-allocated (no HIP call while a stream captures)
 };
 
 namespace {
@@ -63,8 +68,65 @@ ncclResult_t do_recv(const Op &o) {
   if (o.bytes && hipMemcpy(o.rbuf, h.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }
+// ---- stream-ordered mode: file transfer from host callbacks (no HIP call inside them) ----
+bool host_send(ncclComm *c, int peer, const void *data, size_t bytes) {
+  const std::string p = msg_path(c, c->rank, peer, c->sent[peer]++), tmp = p + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  if (bytes && fwrite(data, 1, bytes, f) != bytes) { fclose(f); return false; }
+  fclose(f);
+  return rename(tmp.c_str(), p.c_str()) == 0;
+}
+bool host_recv(ncclComm *c, int peer, void *data, size_t bytes) {
+  const std::string p = msg_path(c, peer, c->rank, c->recvd[peer]++);
+  const auto t0 = std::chrono::steady_clock::now();
+  struct stat st;
+  while (stat(p.c_str(), &st) != 0) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "fake_rccl: rank %d timed out waiting for %s\n", c->rank, p.c_str()); return false; }
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+  if ((size_t)st.st_size != bytes) { fprintf(stderr, "fake_rccl: %s has %lld bytes, receiver expects %zu\n", p.c_str(), (long long)st.st_size, bytes); return false; }
+  FILE *f = fopen(p.c_str(), "rb");
+  if (!f) return false;
+  const bool ok = !bytes || fread(data, 1, bytes, f) == bytes;
+  fclose(f); unlink(p.c_str());
+  return ok;
+}
+struct Node { ncclComm *c; int peer; size_t bytes; void *stage; size_t count; };   // lives as long as the communicator's arena: graphs replay it
+void *arena_take(ncclComm *c, size_t bytes) {
+  const size_t a = (c->arena_used + 63) & ~(size_t)63;
+  if (a + bytes > c->arena_cap) return nullptr;
+  c->arena_used = a + bytes;
+  return c->arena + a;
+}
+void cb_send(void *u) { Node *n = (Node *)u; if (!host_send(n->c, n->peer, n->stage, n->bytes)) fprintf(stderr, "fake_rccl: send failed (rank %d -> %d)\n", n->c->rank, n->peer); }
+void cb_recv(void *u) { Node *n = (Node *)u; if (!host_recv(n->c, n->peer, n->stage, n->bytes)) { fprintf(stderr, "fake_rccl: receive failed (rank %d <- %d)\n", n->c->rank, n->peer); memset(n->stage, 0xff, n->bytes); } }
+void cb_allreduce(void *u) {      // stage: [count doubles mine | count doubles scratch]; result (rank-ordered sum) back into the first part
+  Node *n = (Node *)u; ncclComm *c = n->c;
+  double *mine = (double *)n->stage, *tmp = mine + n->count;
+  for (int p = 0; p < c->world; ++p) host_send(c, p, mine, n->bytes);
+  std::vector<double> acc(n->count, 0.0);
+  for (int p = 0; p < c->world; ++p) { if (!host_recv(c, p, tmp, n->bytes)) { fprintf(stderr, "fake_rccl: all-reduce failed\n"); return; } for (size_t i = 0; i < n->count; ++i) acc[i] += tmp[i]; }
+  memcpy(mine, acc.data(), n->bytes);
+}
+ncclResult_t flush_stream(std::vector<Op> &ops) {
+  for (const Op &o : ops) if (o.send) {
+    Node *n = new Node{o.c, o.peer, o.bytes, arena_take(o.c, o.bytes), 0};
+    if (!n->stage) { fprintf(stderr, "fake_rccl: staging arena exhausted\n"); return ncclSystemError; }
+    if (o.bytes && hipMemcpyAsync(n->stage, o.sbuf, o.bytes, hipMemcpyDeviceToHost, o.s) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipLaunchHostFunc(o.s, cb_send, n) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  for (const Op &o : ops) if (!o.send) {
+    Node *n = new Node{o.c, o.peer, o.bytes, arena_take(o.c, o.bytes), 0};
+    if (!n->stage) { fprintf(stderr, "fake_rccl: staging arena exhausted\n"); return ncclSystemError; }
+    if (hipLaunchHostFunc(o.s, cb_recv, n) != hipSuccess) return ncclUnhandledCudaError;
+    if (o.bytes && hipMemcpyAsync(o.rbuf, n->stage, o.bytes, hipMemcpyHostToDevice, o.s) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  return ncclSuccess;
+}
 ncclResult_t flush() {
   std::vector<Op> ops; ops.swap(g_ops);
+  if (mgs_fake_rccl_marker == 2) return flush_stream(ops);
   for (const Op &o : ops) if (o.send) { ncclResult_t r = do_send(o); if (r != ncclSuccess) return r; }
   for (const Op &o : ops) if (!o.send) { ncclResult_t r = do_recv(o); if (r != ncclSuccess) return r; }
   return ncclSuccess;
@@ -85,10 +147,17 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
   c->dir = std::string("/tmp/") + id.internal; c->world = nranks; c->rank = rank;
   c->sent.assign(nranks, 0); c->recvd.assign(nranks, 0);
   mkdir(c->dir.c_str(), 0700);
+  if (mgs_fake_rccl_marker == 2) {
+    c->arena_cap = (size_t)256 << 20;
+    if (hipHostMalloc((void **)&c->arena, c->arena_cap, hipHostMallocDefault) != hipSuccess) { delete c; return ncclUnhandledCudaError; }
+  }
   *comm = c;
   return ncclSuccess;
 }
-ncclResult_t ncclCommDestroy(ncclComm_t comm) { if (comm) { rmdir(comm->dir.c_str()); delete comm; } return ncclSuccess; }
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+  if (comm) { hipDeviceSynchronize(); if (comm->arena) hipHostFree(comm->arena); rmdir(comm->dir.c_str()); delete comm; }
+  return ncclSuccess;
+}
 const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "success" : "fake_rccl error"; }
 ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { if (--g_depth == 0) return flush(); return ncclSuccess; }
@@ -108,6 +177,14 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
 }
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s) {
   if (t != ncclDouble || op != ncclSum) return ncclInvalidArgument;
+  if (mgs_fake_rccl_marker == 2) {      // stream-ordered: device → pinned, host function (files, rank-ordered sum), pinned → device
+    Node *n = new Node{c, -1, sizeof(double) * count, arena_take(c, 2 * sizeof(double) * count), count};
+    if (!n->stage) return ncclSystemError;
+    if (hipMemcpyAsync(n->stage, send, n->bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipLaunchHostFunc(s, cb_allreduce, n) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipMemcpyAsync(recv, n->stage, n->bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+  }
   double *all = nullptr;
   if (hipMalloc((void **)&all, sizeof(double) * count * c->world) != hipSuccess) return ncclUnhandledCudaError;
   ncclResult_t r = ncclAllGather(send, all, count, t, c, s);

@@ -55,6 +55,27 @@ def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
     assert r.returncode == 0 and "DIST_OK" in r.stdout and "grouped_levels=" in r.stdout and "grouped_levels=0" not in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
+@pytest.mark.parametrize("world,N,tail,opts", [(2, 20, 1500, ""), (3, 18, 800, ""), (2, 40, 3000, ""), (4, 18, 600, ""),
+                                                  (2, 40, 3000, "group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000"), (2, 40, 700, "")])
+def test_native_cycle_captured_in_a_graph_multi_rank(world, N, tail, opts):
+    """The DEFAULT multi-GPU path — native transport with the whole cycle (exchanges, tail all-gather, tail cycle, K-cycle scalars
+    summed over the ranks) captured in one hipGraph — with several ranks on this one GPU: tests/fake_rccl in its stream-ordered mode
+    (device→pinned copy, host function moving the bytes through files, pinned→device copy: capturable like RCCL's kernels).  Asserts
+    in the worker: capture after two eager cycles, replay == eager bit for bit, more (rhs, out) pairs than cache slots, cycle vs the
+    oracle, K-cycle vs the oracle (tail 700: three sharded levels), solve to 1e-10."""
+    fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
+    if not os.path.exists(fake):
+        subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_FAKE_RCCL_STREAM="1")
+    if opts:
+        env["MGS_OPTIONS"] = opts
+    port = 29950 + (os.getpid() % 1000) + world + (7 if opts else 0) + (3 if tail == 700 else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout and "captured_cycles" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
 @pytest.mark.parametrize("world,N,tail", [(2, 20, 1500), (3, 18, 800), (4, 18, 600), (2, 40, 3000)])
 def test_native_transport_multi_rank_matches_oracle(world, N, tail):
     """the NATIVE transport of the C++ cycle (ncclSend/ncclRecv groups, tail all-gather, all-reduced dots) with several

@@ -756,6 +756,59 @@ def test_c4_shaped_standin_three_level_vcycle(ctx, mg, orc):
     assert st == 0 and true <= 1.5e-10, (st, it, tol, true)
 
 
+@pytest.mark.parametrize("kind", ["poisson3d_40", "CSky3d30", "CSky3d30_refP", "random_graph"])
+def test_small_level_pre_pass_and_restriction_in_one_kernel(ctx, mg, orc, inputs, kind):
+    """option aggpre_max_rows (default 100000): on small levels the zero-guess pre pass and the restriction run as ONE aggregate-parallel
+    kernel (agg_pre_kernel) — same arithmetic in the same order as the row-block kernel + restrict_agg_kernel, so the whole cycle has the
+    SAME BITS with the option off; also with the row-block groups off, with aggregates of more than four members (the reference's own
+    P for CSky3d30: up to 8) and with rows outside every aggregate (G0 rows of the convection-diffusion operator)."""
+    P = None
+    if kind.startswith("poisson3d"):
+        A = ctx.poisson3d(int(kind.split("_")[1]))
+    elif kind == "random_graph":
+        import scipy.sparse as sps
+        rng = np.random.default_rng(5)
+        m = 20000
+        i = np.concatenate([np.arange(m - 1), rng.integers(0, m, 2 * m)])
+        j = np.concatenate([np.arange(1, m), np.clip(i[m - 1:] + rng.integers(-30, 31, 2 * m), 0, m - 1)])
+        keep = i != j
+        W = sps.coo_matrix((rng.uniform(0.5, 1.5, keep.sum()), (i[keep], j[keep])), shape=(m, m)).tocsr(); W = W + W.T
+        M = (sps.diags(np.asarray(W.sum(axis=1)).ravel() + 0.02) - W).tocsr(); M.sort_indices()
+        A = ctx.csr(m, m, M.indptr, M.indices, M.data)
+    else:
+        A = mg.Csr.from_mtx(ctx, inputs["CSky3d30"])
+        if kind.endswith("refP"):
+            P = mg.Csr.from_mtx(ctx, inputs["CSky3d30promatrix_cpu"])
+    n = A.shape[0]
+    h = mg.Hierarchy(A, 0.6, 1, 1)
+    if P is not None:
+        h.push_P(P)
+    h.coarsen(10.0, 2, 8.0, 100, 32).finalize()
+    assert h.nlev >= 3
+    b = ctx.vec(n).rand(seed=11)
+    try:
+        ctx.set_option("fuse_restrict", 0)                      # no row-block groups: every level takes the small-level form (or not)
+        ctx.set_option("aggpre_max_rows", 1 << 30); xa = h.vcycle(b).numpy()
+        ctx.set_option("aggpre_max_rows", 0); xs = h.vcycle(b).numpy()
+        assert np.array_equal(xa, xs), rel(xa, xs)
+        ctx.set_option("fuse_restrict", 1)                      # default mix: groups on the big levels, the one-kernel form below
+        ctx.set_option("aggpre_max_rows", 100000); xd = h.vcycle(b).numpy()
+        assert rel(xd, xs) <= 1e-13
+    finally:
+        ctx.set_option("fuse_restrict", 1); ctx.set_option("aggpre_max_rows", 100000)
+    # and against the oracle on the downloaded hierarchy
+    import scipy.sparse as sps
+    As, Ps = [], []
+    for l in range(h.nlev):
+        rp, ci, v = h.level_A(l).download(); r = h.level_shape(l)[0]
+        As.append(orc.Csr.from_arrays(r, r, rp, ci, v))
+        if l < h.nlev - 1:
+            T = h.level_P(l); agg = T.agg(); nf, nc = T.shape; rows = np.nonzero(agg >= 0)[0]
+            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(rows.size), (rows, agg[rows])), shape=(nf, nc))))
+    ho = orc.Hier(As[0], Ps, omega=0.6, nu1=1, nu2=1, As=As)
+    assert rel(xd, ho.vcycle(b.numpy())) <= 1e-10
+
+
 def test_kcycle_vs_oracle(ctx, mg, orc):
     """K-cycle: device-resident GCR scalars; GPU vs the oracle's restatement of the same
     algorithm on the downloaded hierarchy, and fewer Krylov iterations than the V-cycle."""
