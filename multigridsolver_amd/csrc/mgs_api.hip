@@ -119,9 +119,9 @@ static int native_exchange(mgs_hier *h, int l, const double *src, double *dst) {
   size_t so = 0, ro = 0;
   for (int p = 0; p < world; ++p) {
     if (seg) { for (size_t q = 0; q < P->sseg_len[p].size(); ++q) ops.push_back({src + P->sseg_start[p][q], nullptr, (size_t)P->sseg_len[p][q], p}); }
-    else if (P->scnt[p]) ops.push_back({P->sendbuf + so, nullptr, (size_t)P->scnt[p], p});
+    else { size_t q0 = so; for (int len : P->pseg_len[p]) { ops.push_back({P->sendbuf + q0, nullptr, (size_t)len, p}); q0 += (size_t)len; } }      // packed: one message per peer
     if (P->use_seg) { size_t r = ro; for (int len : P->rseg_len[p]) { ops.push_back({nullptr, dst + r, (size_t)len, p}); r += (size_t)len; } }
-    else if (P->rcnt[p]) ops.push_back({nullptr, dst + ro, (size_t)P->rcnt[p], p});
+    else { size_t r = ro; for (int len : P->prseg_len[p]) { ops.push_back({nullptr, dst + r, (size_t)len, p}); r += (size_t)len; } }
     so += (size_t)P->scnt[p]; ro += (size_t)P->rcnt[p];
   }
   return mgs_comm_exchange_ops(P->comm, ops.data(), (int)ops.size());
@@ -263,6 +263,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "kcycle_energy") ctx->opt_kcycle_energy = value;
   else if (k == "aggpre_max_rows") ctx->opt_aggpre_max_rows = value;
   else if (k == "mapmul") ctx->opt_mapmul = value;
+  else if (k == "emu_split_self") ctx->opt_emu_split_self = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them
   return MGS_OK;
@@ -611,6 +612,14 @@ int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int 
     if ((int)P->sseg_len[p].size() > MGS_MAX_SEG) P->seg_ok = false;
     o += (size_t)P->scnt[p];
   }
+  // packed mode: one message per peer.  (Rehearsal of a middle rank on one GPU, option emu_split_self: the buffer the rank sends to
+  // ITSELF stands for the messages to two neighbours — it goes out as two, so packed and pack-free exchanges are timed on equal terms.)
+  P->pseg_len.assign((size_t)world, {}); P->prseg_len.assign((size_t)world, {});
+  for (int p = 0; p < world; ++p) {
+    const bool split = ctx->opt_emu_split_self && world == 1 && P->scnt[p] == P->rcnt[p] && P->scnt[p] >= 2;
+    if (P->scnt[p]) { if (split) { P->pseg_len[p] = {P->scnt[p] / 2, P->scnt[p] - P->scnt[p] / 2}; } else P->pseg_len[p] = {P->scnt[p]}; }
+    if (P->rcnt[p]) { if (split) { P->prseg_len[p] = {P->rcnt[p] / 2, P->rcnt[p] - P->rcnt[p] / 2}; } else P->prseg_len[p] = {P->rcnt[p]}; }
+  }
   L.nx = P;
   h->native = true;
   return MGS_OK;
@@ -627,8 +636,8 @@ int mgs_hier_native_send_segments(const mgs_hier *h, int level, int *nseg, int *
       nseg[p] = (int)P->sseg_len[p].size();
       for (int len : P->sseg_len[p]) { MGS_CHECK(h->ctx, w < cap, MGS_ERR_INVALID, "mgs_hier_native_send_segments: buffer too small"); seglens[w++] = len; }
     } else {
-      nseg[p] = P->scnt[p] ? 1 : 0;
-      if (P->scnt[p]) { MGS_CHECK(h->ctx, w < cap, MGS_ERR_INVALID, "mgs_hier_native_send_segments: buffer too small"); seglens[w++] = P->scnt[p]; }
+      nseg[p] = (int)P->pseg_len[p].size();
+      for (int len : P->pseg_len[p]) { MGS_CHECK(h->ctx, w < cap, MGS_ERR_INVALID, "mgs_hier_native_send_segments: buffer too small"); seglens[w++] = len; }
     }
   }
   return w;

@@ -60,6 +60,7 @@ struct mgs_ctx {
   int opt_blas1_pairs = 1;    // ... pairs per lane of those kernels: 1 = one-shot workgroups (0: capped persistent grid, k: k pairs per lane)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
   int opt_aggpre_max_rows = 100000;   // levels with at most this many rows run pre pass + restriction as ONE aggregate-parallel kernel (launch-bound sizes; same bits)
+  int opt_emu_split_self = 0;   // tools/emulate_rank.py only: a packed exchange with the rank itself goes out as two messages (a middle rank has two neighbours)
   int opt_mapmul = 1;    // strip-major block map: quotients by multiply-high instead of two integer divisions at the head of every wave
   int opt_kcycle_energy = 0;  // K-cycle coefficients from energy inner products (flexible-CG form; SPD operators) instead of the GCR form of the paper
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
@@ -154,6 +155,7 @@ struct mgs_native_plan {
   // its own decision (sseg, from send_idx); what it receives it is told by its peers (rseg, shipped by the host side at setup:
   // mgs_hier_native_send_segments → mgs_hier_set_native_recv_segments, which also switches this rank's sends to ranges).
   std::vector<std::vector<int>> sseg_start, sseg_len, rseg_len;   // per peer
+  std::vector<std::vector<int>> pseg_len, prseg_len;              // per peer: message lengths of the packed form (one per peer; see emu_split_self)
   bool seg_ok = false;      // every peer's send list splits into at most MGS_MAX_SEG ranges
   bool use_seg = false;     // receive segmentation installed on this rank (collective call): sends go out as ranges
 };

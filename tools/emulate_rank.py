@@ -20,6 +20,9 @@ dist.init_process_group("nccl")
 torch.cuda.set_device(0)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 ctx = mg.Context(0, stream.cuda_stream)
+if R >= 3 and os.environ.get("EMU_SPLIT", "1") != "0":
+    ctx.set_option("emu_split_self", 1)     # a middle rank talks to two neighbours: a packed exchange with itself goes out as two messages too
+                                            # (EMU_SPLIT=0: one message, the convention of the round-2 rehearsals)
 comm = mgd.Comm()
 lo, hi = mgd.plane_range(N, R, R // 2)
 n2 = N * N; n_loc = (hi - lo) * n2

@@ -107,7 +107,13 @@ if cyc_t and nd_f == len(cyc_t) and nd_w == len(cyc_t):
               "wall_ms": (int(cyc_t[-1]["End_Timestamp"]) - int(cyc_t[0]["Start_Timestamp"])) / 1e6,
               "hbm_read_bytes_corrected": rd, "hbm_write_bytes_corrected": wr, "traffic_bytes": rd + wr,
               "note": "sum over every dispatch of the last V-cycle of the workload (eager launches), FETCH_SIZE/WRITE_SIZE passes corrected like the per-kernel rows"}
-summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "vcycle": vcycle, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
+import subprocess
+try:      # the commit whose build was profiled (the summary is written in the build container, right after the GPU call that ran this snapshot)
+    code_commit = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    dirty = bool(subprocess.run(["git", "-C", REPO, "status", "--porcelain", "--", "multigridsolver_amd", "include", "bench.py", "tools/prof_workload.py"], capture_output=True, text=True).stdout.strip())
+except Exception:  # noqa: BLE001
+    code_commit, dirty = None, None
+summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "code_commit": code_commit, "code_dirty": dirty, "vcycle": vcycle, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
            "fetch_size_correction": cal_read, "write_size_correction": cal_write,
            "note": "FETCH_SIZE on gfx950 reports half the bytes of this access pattern (8-byte lanes): calibrated on axpby's known 16n read bytes; "
                    "counters come from L2's fabric-side requests, so Infinity-Cache hits are included (traffic >= HBM bytes). "
