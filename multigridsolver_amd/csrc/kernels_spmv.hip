@@ -82,7 +82,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // planes of the XCD's range, so x[e+N²] fetched for plane p is still in L2 when planes p+1 and
 // p+2 need it as x[e] and x[e−N²].  Pure permutation: every row block is visited exactly once.
 struct BlockMap { int nblocks, chunk, remap, D, S, P, base, gap_at = 0x7fffffff, gap_len = 0;
-                  unsigned mps = 0, mS = 0; };   // ⌊2³²/(P·S)⌋+1 and ⌊2³²/S⌋+1: quotients by multiply-high (0: divide) — set by finish_map
+                  unsigned mps = 0, mS = 0; };   // ⌊2³²/(P·S)⌋+1 and ⌊2³²/S⌋+1: quotients by multiply-high — set by strip_map with D, S, P
 // base: first row block of the launched range;
 // row blocks >= gap_at are shifted by gap_len (one launch over the leading + trailing boundary blocks of a row shard)
 __device__ __forceinline__ int block_of(const BlockMap &m, int vb) { const int b = m.base + vb; return b >= m.gap_at ? b + m.gap_len : b; }
@@ -94,11 +94,12 @@ __device__ __forceinline__ int map_block(const BlockMap &m, int bid) {
 __device__ __forceinline__ int map_block_xi(const BlockMap &m, int xcd, int idx) {
   int lb = idx;
   if (m.D > 0) {
-    // (the two integer divisions of this map compiled to ~70 dependent scalar instructions at the head of EVERY wave, in front of its first
-    //  load: a quotient by multiply-high is two.  Exact for idx·divisor < 2³², which finish_map checks on the host.)
+    // Quotients by multiply-high (m.mps = ⌊2³²/(P·S)⌋+1, m.mS = ⌊2³²/S⌋+1; exact for idx·divisor < 2³², which the host checks — it
+    // falls back to the plain XCD-contiguous map otherwise).  The two integer divisions this replaces compiled to ~65 dependent scalar
+    // instructions at the head of EVERY wave, in front of its first load (and stayed there, if-converted, behind a run-time switch).
     const int ps = m.P * m.S;
-    const int s = m.mps ? (int)__umulhi((unsigned)idx, m.mps) : idx / ps, rem = idx - s * ps;
-    const int p = m.mS ? (int)__umulhi((unsigned)rem, m.mS) : rem / m.S, t = rem - p * m.S;
+    const int s = (int)__umulhi((unsigned)idx, m.mps), rem = idx - s * ps;
+    const int p = (int)__umulhi((unsigned)rem, m.mS), t = rem - p * m.S;
     const int off = s * m.S + t;
     if (off >= m.D) return -1;
     lb = p * m.D + off;
@@ -1395,14 +1396,18 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 }
 
 
-// multiply-high constants of a strip-major map (see map_block_xi); grid_x = workgroups of the launch
-static void finish_map(const mgs_ctx *ctx, BlockMap &bm, unsigned grid_x) {
-  bm.mps = bm.mS = 0;
-  if (!ctx->opt_mapmul || bm.D <= 0 || bm.S <= 0 || bm.P <= 0) return;
-  const unsigned long long ps = (unsigned long long)bm.P * (unsigned long long)bm.S, nmax = grid_x / 8 + 1;
-  if (nmax * ps >= (1ull << 32) || ps * (unsigned long long)bm.S >= (1ull << 32)) return;     // quotient not exact by this method: divide
+// strip-major sweep of period D (row blocks or groups) with strips of S: installs D, S, P and the multiply-high constants of
+// map_block_xi and returns the workgroups per XCD — or leaves the plain XCD-contiguous map (returns bm.chunk) where a quotient would
+// not be exact by multiply-high (idx·divisor ≥ 2³²: never at the sizes 288 GB hold, checked all the same)
+static int strip_map(BlockMap &bm, int D, int S) {
+  const int P = (bm.chunk + D - 1) / D;
+  const int per_xcd = ((D + S - 1) / S) * P * S;
+  const unsigned long long ps = (unsigned long long)P * (unsigned long long)S;
+  if (D <= 0 || S <= 0 || ((unsigned long long)per_xcd + 1) * ps >= (1ull << 32) || ps * (unsigned long long)S >= (1ull << 32)) { bm.D = bm.S = bm.P = 0; return bm.chunk; }
+  bm.D = D; bm.S = S; bm.P = P;
   bm.mps = (unsigned)((1ull << 32) / ps) + 1u;
-  bm.mS = (unsigned)((1ull << 32) / (unsigned long long)bm.S) + 1u;
+  bm.mS = (unsigned)((1ull << 32) / (unsigned long long)S) + 1u;
+  return per_xcd;
 }
 // workgroup → group map: XCD-contiguous, strip-major for far bands (distances in groups instead of row blocks)
 static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) {
@@ -1416,13 +1421,11 @@ static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) 
     const int Db = (A->far_band + RB - 1) / RB;
     const int D = G->plane_groups;          // groups from one far-band period to the next (setup: first blocks Db apart)
     if (Db >= 512 && D >= 64 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_group_strip > 0 ? ctx->opt_group_strip : (ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 128); bm.P = (bm.chunk + D - 1) / D;
+      per_xcd = strip_map(bm, D, ctx->opt_group_strip > 0 ? ctx->opt_group_strip : (ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / 2) : 128));
       // strip of 128 groups by default: 512³, same-process sweep 5.51 / 5.46 / 5.42 / 5.40 / 5.40 / 5.51 ms per cycle for 2 / 16 / 32 / 64 / 128 / 512 groups
-      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
     }
   }
   const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
-  finish_map(ctx, bm, grid.x);
   return grid;
 }
 
@@ -1615,12 +1618,10 @@ static dim3 plan_block_map(const mgs_csr *A, int blk_lo, int blk_hi, BlockMap &b
   if (bm.remap && ctx->opt_strip != 0) {
     const int D = (A->far_band + RB - 1) / RB;
     if (D >= 512 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
-      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+      per_xcd = strip_map(bm, D, ctx->opt_strip > 0 ? ctx->opt_strip : 64);
     }
   }
   const dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
-  finish_map(ctx, bm, grid.x);
   return grid;
 }
 
@@ -1663,12 +1664,10 @@ int mgs_launch_fused_range(const mgs_csr *A, int which, const double *wd, const 
   if (bm.remap && ctx->opt_strip != 0) {
     const int D = (A->far_band + RB - 1) / RB;
     if (D >= 512 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
-      per_xcd = ((D + bm.S - 1) / bm.S) * bm.P * bm.S;
+      per_xcd = strip_map(bm, D, ctx->opt_strip > 0 ? ctx->opt_strip : 64);
     }
   }
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
-  finish_map(ctx, bm, grid.x);
   const int cap = A->lds_cap;
   const size_t lds = (size_t)(cap + 2) * 12 + 16;
   if (which == FUSE_POST_MAPPED && use_rowcode(A, A->code))      // A is the view whose col/code are the aggregate-mapped ones
@@ -1702,9 +1701,7 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
   if (bm.remap && ctx->opt_strip != 0) {
     const int D = (A->far_band + RB - 1) / RB;
     if (D >= 512 && bm.chunk >= 2 * D) {
-      bm.D = D; bm.S = ctx->opt_strip > 0 ? ctx->opt_strip : 64; bm.P = (bm.chunk + D - 1) / D;
-      const int strips = (D + bm.S - 1) / bm.S;
-      per_xcd = strips * bm.P * bm.S;
+      per_xcd = strip_map(bm, D, ctx->opt_strip > 0 ? ctx->opt_strip : 64);
     }
   }
   int cap = ctx->opt_spmv_variant == 1 ? -1 : A->lds_cap;
@@ -1721,8 +1718,7 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
     if (sm.remap && ctx->opt_strip != 0) {
       const int D = ((A->far_band + RB - 1) / RB + G - 1) / G;
       if (D >= 64 && sm.chunk >= 2 * D) {
-        sm.D = D; sm.S = ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / G) : 16; sm.P = (sm.chunk + D - 1) / D;
-        per = ((D + sm.S - 1) / sm.S) * sm.P * sm.S;
+        per = strip_map(sm, D, ctx->opt_strip > 0 ? std::max(1, ctx->opt_strip / G) : 16);
       }
     }
     // base stays in row-block units inside the kernel: bm.base + first + j
@@ -1750,7 +1746,6 @@ int mgs_launch_csr_op_range(const mgs_csr *A, int op, const double *x, const dou
     return MGS_OK;
   }
   dim3 grid(bm.remap ? per_xcd * 8 : bm.nblocks);
-  finish_map(ctx, bm, grid.x);
   if (ctx->opt_spmv_variant == 0 && !ctx->opt_nontemporal && use_rowcode(A, A->code))
     return launch_coded(A, A->code, op, A->col, x, b, dinv, omega, nullptr, nullptr, out, grid, bm);
   size_t lds = sizeof(double) * (size_t)(cap > 0 ? cap : 1);

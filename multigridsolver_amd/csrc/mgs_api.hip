@@ -262,7 +262,6 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "stage_unroll") ctx->opt_stage_unroll = value;
   else if (k == "kcycle_energy") ctx->opt_kcycle_energy = value;
   else if (k == "aggpre_max_rows") ctx->opt_aggpre_max_rows = value;
-  else if (k == "mapmul") ctx->opt_mapmul = value;
   else if (k == "emu_split_self") ctx->opt_emu_split_self = value;
   else return mgs_fail(ctx, MGS_ERR_INVALID, "unknown option '%s'", k.c_str());
   ++ctx->opt_epoch;      // every captured cycle was recorded under the old options: mgs_vcycle drops them

@@ -61,7 +61,6 @@ struct mgs_ctx {
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
   int opt_aggpre_max_rows = 100000;   // levels with at most this many rows run pre pass + restriction as ONE aggregate-parallel kernel (launch-bound sizes; same bits)
   int opt_emu_split_self = 0;   // tools/emulate_rank.py only: a packed exchange with the rank itself goes out as two messages (a middle rank has two neighbours)
-  int opt_mapmul = 1;    // strip-major block map: quotients by multiply-high instead of two integer divisions at the head of every wave
   int opt_kcycle_energy = 0;  // K-cycle coefficients from energy inner products (flexible-CG form; SPD operators) instead of the GCR form of the paper
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph
   int opt_native_overlap = 0; // ... and, inside that graph, run the interior row blocks on a second stream beside pack + exchange (measured on one GPU:

@@ -3,6 +3,8 @@ oracle on the same seeded inputs and against the committed golden vectors of the
 reference.  Bars: bit-exact where the summation order is the reference's (row-block stream
 kernel, aggregation transfer); ≤1e-13 relative for re-ordered sums (long-row path, dots);
 ≤1e-10 per V-cycle application (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1175,3 +1177,49 @@ def test_value_pattern_coding_bit_identical(ctx, mg, orc):
             assert res[1][3]["coded_blocks"] >= res[1][3]["blocks"] - 1 and res[1][4]["coded_col_agg"] > 0, res[1][3:]
         else:
             assert res[1][3]["coded_blocks"] == 0, res[1][3]
+
+
+def test_device_memory_arena_same_bits_and_reuse():
+    """mgs_arena_reserve / MGS_ARENA_GB: every device allocation of the library is placed inside one hipMalloc (first fit, coalescing on
+    release), requests that do not fit fall through to hipMalloc.  In a process of its own (the arena is per process): the cycle and
+    the solve give the SAME BITS as without an arena, released blocks are reused (the second hierarchy does not grow the footprint),
+    an arena too small for a request still works, and mgs_arena_info accounts for what is in use."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = r'''
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, %r)
+import multigridsolver_amd as mg
+L = mg.lib()
+def info():
+    out = (C.c_size_t * 3)(); assert L.mgs_arena_info(out) == 0; return [int(v) for v in out]
+def run(ctx, N):
+    A = ctx.poisson3d(N); n = N ** 3
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 200, 32).finalize()
+    b = ctx.vec(n).rand(seed=4); x = h.vcycle(b).numpy()
+    xs = ctx.vec(n); st, it, tol = mg.bicgstab(A, xs, b, h, 300, 1e-10)
+    assert st == 0
+    return x, xs.numpy(), it
+ctx = mg.Context(0)
+cap = info()[0]
+x1, s1, it1 = run(ctx, 48)
+used_after_1 = info()[1]
+ctx.trim()
+x2, s2, it2 = run(ctx, 48)                      # released blocks are found again: same footprint, same results
+assert np.array_equal(x1, x2) and np.array_equal(s1, s2) and it1 == it2
+if cap:
+    assert info()[0] == cap and 0 < info()[1] <= cap
+    xb, sb, itb = run(ctx, 96)                  # does not fit a 64 MiB arena as a whole: the overflow goes to hipMalloc, results unaffected
+    assert itb > 0
+ctx.close()
+print("ARENA", cap, x1.tobytes().hex()[:64], np.float64(s1).sum().hex(), it1)
+''' % REPO
+    outs = {}
+    for gb in ("0", "0.0625"):
+        env = dict(os.environ, MGS_ARENA_GB=gb)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+        assert r.returncode == 0 and "ARENA" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[gb] = r.stdout.strip().split("\n")[-1].split()
+    assert outs["0"][1] == "0" and int(outs["0.0625"][1]) == 64 << 20, outs
+    assert outs["0"][2:] == outs["0.0625"][2:], "results differ with the arena"

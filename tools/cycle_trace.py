@@ -10,8 +10,9 @@ def short(n): return n.replace("(anonymous namespace)::", "").replace("void ", "
 names = [short(r["Kernel_Name"]) for r in rows]
 # a cycle starts at the largest-grid residual-form kernel ("<1," pre pass) and ends with the largest-grid post pass ("<5,")
 gx = [int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]) for r in rows]
-big = max(gx)
-ends = [i for i, (n, g) in enumerate(zip(names, gx)) if g == big and ("kernel<5" in n or "kernel<4" in n)]
+post = [i for i, n in enumerate(names) if "kernel<5" in n or "kernel<4" in n]
+big = max(gx[i] for i in post)          # the fine-level post pass: the largest grid among the post-pass kernels
+ends = [i for i in post if gx[i] == big]
 e = ends[-1]; s = ends[-2] + 1          # a cycle = everything between two fine-level post passes
 out = []
 t_first = int(rows[s]["Start_Timestamp"]); t_last = int(rows[e]["End_Timestamp"])

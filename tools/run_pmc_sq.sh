@@ -7,6 +7,7 @@ OUT=$ROOT/gpurun_out/pmc_sq
 GRID=${1:-512}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+export MGS_ARENA_GB=${MGS_ARENA_GB:-100}     # the arena bench.py reserves by default: same placement policy in the profiled workload
 [ -n "$2" ] && export MGS_OPTIONS="$2"
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/tools/prof_workload.py $GRID 2 > $OUT/$name.log 2>&1; echo "pass $name done"; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

@@ -7,6 +7,7 @@ OUT=$ROOT/gpurun_out/prof
 GRID=${1:-512}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+export MGS_ARENA_GB=${MGS_ARENA_GB:-100}     # the arena bench.py reserves by default: same placement policy in the profiled workload
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/tools/prof_workload.py $GRID 5 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/prof_workload.py $GRID 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/prof_workload.py $GRID 2 > $OUT/pmc_write.log 2>&1
