@@ -130,3 +130,28 @@ def test_handshake_and_exchange_gloo(WORLD):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_export_zones_and_range_expansion_of_coarse_halo():
+    """Pure host logic of the pack-free exchanges (multigridsolver_amd/dist.py): zones of the exported rows (one per peer and contiguous
+    run of its list, 0 = interior), and coarse_plan_handshake's cluster-wise filling of nearly contiguous id lists — a scattered
+    prefix + a far block stay two ranges, a cluster is filled only within the slack, −1 (G0) rows get no slot."""
+    sys.path.insert(0, REPO)
+    from multigridsolver_amd import dist as mgd
+    plan = mgd.LevelPlan(100, [np.array([90, 91, 92, 0, 1, 2, 3], np.int32), np.zeros(0, np.int32)], [np.zeros(0, np.int32)] * 2)
+    z = mgd.export_zones(plan)
+    assert z[:4].tolist() == [2, 2, 2, 2] and z[90:93].tolist() == [1, 1, 1] and z[4:90].sum() == 0 and z[93:].sum() == 0
+    # one "peer" = this rank itself (the one-GPU rehearsal): its list is [last rows, first rows]; the aggregates of the first rows
+    # are ids 0..3, those of the last rows 40, 42, 43, 45 plus one far straggler 7 → clusters {0..3, 7} and {40..45}
+    plan = mgd.LevelPlan(16, [np.arange(16, dtype=np.int32)], [np.arange(16, dtype=np.int32)])
+    agg = np.array([40, 42, 43, 45, 40, 42, -1, 45, 0, 1, 2, 3, 0, 7, 2, 3], dtype=np.int32)
+    ex = lambda lists: [np.asarray(a, dtype=np.int64).copy() for a in lists]        # world 1: the "peer" gets its own lists back
+    cols, n_halo_c, cplan = mgd.coarse_plan_handshake(plan, agg, 50, ex, span_slack=2.5)
+    u = cplan.recv_ids[0].tolist()
+    assert u == [0, 1, 2, 3, 4, 5, 6, 7, 40, 41, 42, 43, 44, 45], u              # {0..7}: 8 slots for 5 ids (≤ 2.5×); {40..45}: 6 for 4
+    assert n_halo_c == len(u) and cols[6] == -1 and cols[0] == 50 + u.index(40) and cols[13] == 50 + u.index(7)
+    assert cplan.send_idx[0].tolist() == u
+    cols, n_halo_c, cplan = mgd.coarse_plan_handshake(plan, agg, 50, ex, span_slack=1.2)
+    assert cplan.recv_ids[0].tolist() == [0, 1, 2, 3, 7, 40, 42, 43, 45]                 # nothing within 1.2×: the lists stay as they are
+    cols, n_halo_c, cplan = mgd.coarse_plan_handshake(plan, agg, 50, ex, span_slack=1.0)
+    assert cplan.recv_ids[0].tolist() == [0, 1, 2, 3, 7, 40, 42, 43, 45]
