@@ -26,6 +26,7 @@ def main(argv=None):
     ap.add_argument("--max-iter", type=int, default=10000)       # bicg.cpp:164
     ap.add_argument("--solver", choices=["bicgstab", "fgcr"], default="bicgstab")
     ap.add_argument("--kcycle", type=int, default=0)
+    ap.add_argument("--kcycle-energy", action="store_true", help="K-cycle coefficients from energy inner products (flexible-CG form; symmetric positive definite operators only)")
     ap.add_argument("--omega", type=float, default=0.6)
     ap.add_argument("--nu1", type=int, default=1)
     ap.add_argument("--nu2", type=int, default=1)
@@ -44,6 +45,8 @@ def main(argv=None):
     bg = ref_rhs(rows)
     if world == 1:
         ctx = mg.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        if args.kcycle_energy:
+            ctx.set_option("kcycle_energy", 1)
         A = ctx.csr(rows, cols, rp, ci, v)
         h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2)
         if args.P:
