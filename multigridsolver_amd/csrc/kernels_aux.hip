@@ -146,9 +146,23 @@ __global__ __launch_bounds__(TB) void agg_pre_kernel(int n, int nc, const int *_
                                                       double *__restrict__ r_out, double *__restrict__ rc_out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   auto row_residual = [&](int m) -> double {
+    // eight entries per step, every load of a step issued before the first is waited for (a loop over single entries drains its
+    // loads at every header: two serialized memory latencies per ENTRY); the sum itself stays sequential in ascending column order
     double s = 0.0;
-    for (int e = rowptr[m], ee = rowptr[m + 1]; e < ee; ++e) { const int c = col[e]; s += valhat[e] * (c < n ? b[c] : hv[c - n]); }
-    return b[m] - s;
+    const int e0 = rowptr[m], ee = rowptr[m + 1];
+    const double bm = b[m];
+    for (int e = e0; e < ee; e += 8) {
+      int c[8]; double v[8], xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] = e + q < ee ? col[e + q] : -1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = e + q < ee ? valhat[e + q] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = c[q] < 0 ? 0.0 : (c[q] < n ? b[c[q]] : hv[c[q] - n]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (e + q < ee) s += v[q] * xv[q];
+    }
+    return bm - s;
   };
   const int a = t >> 2, q = t & 3;
   if (a < nc) {                                   // the four lanes of a group share a: same trip counts, converged shuffles

@@ -59,7 +59,7 @@ struct mgs_ctx {
   int opt_stage_unroll = 1;   // row-block kernels stage their value slice without a loop in front of the barrier (predicated 16-byte loads / LDS-DMA): −4 … −7 % per cycle
   int opt_blas1_pairs = 1;    // ... pairs per lane of those kernels: 1 = one-shot workgroups (0: capped persistent grid, k: k pairs per lane)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)
-  int opt_aggpre_max_rows = 100000;   // levels with at most this many rows run pre pass + restriction as ONE aggregate-parallel kernel (launch-bound sizes; same bits)
+  int opt_aggpre_max_rows = 300000;   // levels with at most this many rows run pre pass + restriction as ONE aggregate-parallel kernel (launch-bound sizes; same bits)
   int opt_emu_split_self = 0;   // tools/emulate_rank.py only: a packed exchange with the rank itself goes out as two messages (a middle rank has two neighbours)
   int opt_kcycle_energy = 0;  // K-cycle coefficients from energy inner products (flexible-CG form; SPD operators) instead of the GCR form of the paper
   int opt_native_graph = 1;   // row shards on the native RCCL transport: capture the whole cycle (exchanges included) in a hipGraph

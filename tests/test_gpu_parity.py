@@ -760,7 +760,7 @@ def test_c4_shaped_standin_three_level_vcycle(ctx, mg, orc):
 
 @pytest.mark.parametrize("kind", ["poisson3d_40", "CSky3d30", "CSky3d30_refP", "random_graph"])
 def test_small_level_pre_pass_and_restriction_in_one_kernel(ctx, mg, orc, inputs, kind):
-    """option aggpre_max_rows (default 100000): on small levels the zero-guess pre pass and the restriction run as ONE aggregate-parallel
+    """option aggpre_max_rows (default 300000): on small levels the zero-guess pre pass and the restriction run as ONE aggregate-parallel
     kernel (agg_pre_kernel) — same arithmetic in the same order as the row-block kernel + restrict_agg_kernel, so the whole cycle has the
     SAME BITS with the option off; also with the row-block groups off, with aggregates of more than four members (the reference's own
     P for CSky3d30: up to 8) and with rows outside every aggregate (G0 rows of the convection-diffusion operator)."""
@@ -794,10 +794,10 @@ def test_small_level_pre_pass_and_restriction_in_one_kernel(ctx, mg, orc, inputs
         ctx.set_option("aggpre_max_rows", 0); xs = h.vcycle(b).numpy()
         assert np.array_equal(xa, xs), rel(xa, xs)
         ctx.set_option("fuse_restrict", 1)                      # default mix: groups on the big levels, the one-kernel form below
-        ctx.set_option("aggpre_max_rows", 100000); xd = h.vcycle(b).numpy()
+        ctx.set_option("aggpre_max_rows", 300000); xd = h.vcycle(b).numpy()
         assert rel(xd, xs) <= 1e-13
     finally:
-        ctx.set_option("fuse_restrict", 1); ctx.set_option("aggpre_max_rows", 100000)
+        ctx.set_option("fuse_restrict", 1); ctx.set_option("aggpre_max_rows", 300000)
     # and against the oracle on the downloaded hierarchy
     import scipy.sparse as sps
     As, Ps = [], []
