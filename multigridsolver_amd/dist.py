@@ -491,7 +491,7 @@ class ShardedHierarchy:
             check(lib().mgs_hier_set_native_tail(self.h.h, c, self.tail.h, nl.ctypes.data_as(C.c_void_p)), ctx.h)
             # global tail row of every halo slot of the last sharded level: the level above reads e_c straight from the tail's solution
             lp = self.plans[-1]
-            if lp.n_halo and os.environ.get("MGS_TAIL_ALIAS", "1") != "0":
+            if lp.n_halo and os.environ.get("MGS_TAIL_HALO", "1") != "0":
                 hg = np.concatenate([self.tail_offs[p] + ids.astype(np.int64) for p, ids in enumerate(lp.recv_ids)]).astype(np.int32)
                 check(lib().mgs_hier_set_native_tail_halo(self.h.h, hg.ctypes.data_as(C.c_void_p), int(hg.size)), ctx.h)
         except Exception as e:  # noqa: BLE001
