@@ -567,7 +567,7 @@ static inline int grid_vec(int64_t n2, const mgs_ctx *ctx) {
 // per-workgroup partial pairs of a one-shot reduction launch ([2][nb] doubles; grown outside any capture)
 int mgs_ensure_dot_part(mgs_ctx *ctx, int64_t doubles) {
   if (ctx->dot_part_cap >= doubles) return MGS_OK;
-  if (ctx->dot_part) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(ctx->dot_part); ctx->dot_part = nullptr; ctx->dot_part_cap = 0; }
+  if (ctx->dot_part) { MGS_HIP(ctx, hipStreamSynchronize(ctx->stream)); mgs_hip_free(ctx->dot_part); ctx->dot_part = nullptr; ctx->dot_part_cap = 0; }
   MGS_TRY(mgs_dev_alloc(ctx, &ctx->dot_part, (size_t)doubles));
   ctx->dot_part_cap = doubles;
   return MGS_OK;
@@ -587,7 +587,7 @@ int k_diag_inv(const mgs_csr *A, double *dinv, int *bad_count_host) {
     hipLaunchKernelGGL(diag_inv_kernel, dim3(mgs_grid(A->rows, TB)), dim3(TB), 0, ctx->stream, A->rows, A->rowptr, A->col, A->val, dinv, bad);
   MGS_HIP(ctx, hipMemcpyAsync(bad_count_host, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MGS_HIP(ctx, hipFree(bad));
+  MGS_HIP(ctx, mgs_hip_free(bad));
   return MGS_OK;
 }
 
@@ -872,8 +872,8 @@ int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out) {
   int h[2] = {0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, piv, sizeof h, hipMemcpyDeviceToHost, s));
   MGS_HIP(ctx, hipStreamSynchronize(s));
-  MGS_HIP(ctx, hipFree(W)); MGS_HIP(ctx, hipFree(colk)); MGS_HIP(ctx, hipFree(piv));
-  if (h[1]) { hipFree(inv); return mgs_fail(ctx, MGS_ERR_NUMERIC, "coarsest operator (%d rows) is singular", n); }
+  MGS_HIP(ctx, mgs_hip_free(W)); MGS_HIP(ctx, mgs_hip_free(colk)); MGS_HIP(ctx, mgs_hip_free(piv));
+  if (h[1]) { mgs_hip_free(inv); return mgs_fail(ctx, MGS_ERR_NUMERIC, "coarsest operator (%d rows) is singular", n); }
   *inv_out = inv;
   return MGS_OK;
 }

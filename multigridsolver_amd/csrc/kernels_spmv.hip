@@ -1223,7 +1223,7 @@ int mgs_plan_csr(mgs_csr *A) {
   A->lds_cap = 0;
   if (A->rows == 0) return MGS_OK;
   int nblocks = (A->rows + RB - 1) / RB;
-  if (A->blkptr) { hipFree(A->blkptr); A->blkptr = nullptr; }
+  if (A->blkptr) { mgs_hip_free(A->blkptr); A->blkptr = nullptr; }
   MGS_TRY(mgs_dev_alloc(ctx, &A->blkptr, (size_t)nblocks + 1));
   hipLaunchKernelGGL(blkptr_kernel, dim3((nblocks + 256) / 256), dim3(256), 0, ctx->stream, A->rows, A->rowptr, nblocks, A->blkptr);
   int *d = nullptr;
@@ -1235,7 +1235,7 @@ int mgs_plan_csr(mgs_csr *A) {
   int h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   MGS_HIP(ctx, hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MGS_HIP(ctx, hipFree(d));
+  MGS_HIP(ctx, mgs_hip_free(d));
   A->max_row_len = h[1];
   // typical far-band distance = mean over rows of the row's farthest owned column (the max is set by a few
   // odd-shaped boundary aggregates on coarse levels and would mis-size the strip-major sweep)
@@ -1269,7 +1269,7 @@ int mgs_plan_csr(mgs_csr *A) {
     int over[4] = {0, 0, 0, 0};
     MGS_HIP(ctx, hipMemcpyAsync(over, dc, sizeof over, hipMemcpyDeviceToHost, ctx->stream));
     MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MGS_HIP(ctx, hipFree(dc));
+    MGS_HIP(ctx, mgs_hip_free(dc));
     for (int q = 0; q < 4; ++q)
       if (cand[q] < A->lds_cap && over[q] <= 0.015 * nblocks) { A->lds_cap = cand[q]; break; }
   }
@@ -1326,18 +1326,18 @@ int mgs_build_rowcode(mgs_ctx *ctx, int n, const int *rowptr, const int *idx, co
       }
     }
   }
-  if (isrep) hipFree(isrep);
-  if (ints) hipFree(ints);
+  if (isrep) mgs_hip_free(isrep);
+  if (ints) mgs_hip_free(ints);
   if (rc != MGS_OK || !c->coded_blocks) { mgs_free_rowcode(c); c = nullptr; }
   *out = c;
   return rc;
 }
 void mgs_free_rowcode(mgs_rowcode *c) {
   if (!c) return;
-  if (c->pid) hipFree(c->pid);
-  if (c->tptr) hipFree(c->tptr);
-  if (c->tab) hipFree(c->tab);
-  if (c->vtab) hipFree(c->vtab);
+  if (c->pid) mgs_hip_free(c->pid);
+  if (c->tptr) mgs_hip_free(c->tptr);
+  if (c->tab) mgs_hip_free(c->tab);
+  if (c->vtab) mgs_hip_free(c->vtab);
   delete c;
 }
 
@@ -1431,8 +1431,8 @@ static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) 
 
 void mgs_free_groups(mgs_groups *g) {
   if (!g) return;
-  if (g->gblk) hipFree(g->gblk); if (g->afirst) hipFree(g->afirst); if (g->acode) hipFree(g->acode); if (g->gdesc) hipFree(g->gdesc);
-  if (g->wmask) hipFree(g->wmask); if (g->stray) hipFree(g->stray);
+  if (g->gblk) mgs_hip_free(g->gblk); if (g->afirst) mgs_hip_free(g->afirst); if (g->acode) mgs_hip_free(g->acode); if (g->gdesc) mgs_hip_free(g->gdesc);
+  if (g->wmask) mgs_hip_free(g->wmask); if (g->stray) mgs_hip_free(g->stray);
   delete g;
 }
 // Pairs the row blocks of A along its aggregates (see csr_group_pre_kernel).  *out stays NULL when the level does not
@@ -1548,7 +1548,7 @@ int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_grou
       usable = rc == MGS_OK;
     }
   }
-  if (vkey) hipFree(vkey); if (vcnt) hipFree(vcnt); if (flags) hipFree(flags); if (blk2grp) hipFree(blk2grp);
+  if (vkey) mgs_hip_free(vkey); if (vcnt) mgs_hip_free(vcnt); if (flags) mgs_hip_free(flags); if (blk2grp) mgs_hip_free(blk2grp);
   if (getenv("MGS_DEBUG_GROUPS"))
     fprintf(stderr, "[mgs groups] n=%d nc=%d blocks=%d: ids ascending=%d groups=%d strays=%d (limit %d%%) -> %s\n", n, nc, nblocks, hflags[0] == 0,
             G->ngroups, G->nstray, ctx->opt_group_stray_pct, usable ? "grouped" : "separate kernels");

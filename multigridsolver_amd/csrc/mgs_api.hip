@@ -8,8 +8,6 @@
 thread_local std::string g_mgs_last_error;
 
 // ------------------------------------------------------------------ device memory arena (see mgs_internal.hpp)
-#undef hipMalloc
-#undef hipFree
 #include <map>
 #include <mutex>
 namespace {
@@ -93,8 +91,6 @@ hipError_t mgs_hip_free(void *p) {
   }
   return hipFree(p);
 }
-#define hipMalloc(p, n) mgs_hip_malloc((void **)(p), (n))
-#define hipFree(p) mgs_hip_free((void *)(p))
 
 int mgs_fail(mgs_ctx *ctx, int code, const char *fmt, ...) {
   char buf[1024];
@@ -181,7 +177,7 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   c->red_cap = 4096 + 64;    // DOT_BLOCKS partials + the folded results (kernels_aux.hip)
-  if (hipMalloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+  if (mgs_hip_malloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
   }
   for (int q = 0; q < 16; ++q) c->red_host[q] = 0.0;
@@ -208,8 +204,8 @@ int mgs_ctx_destroy(mgs_ctx *c) {
   hipStreamSynchronize(c->stream);
   for (mgs_vec *v : c->ws_free) mgs_vec_destroy(v);
   c->ws_free.clear();
-  if (c->red_dev) hipFree(c->red_dev);
-  if (c->dot_part) hipFree(c->dot_part);
+  if (c->red_dev) mgs_hip_free(c->red_dev);
+  if (c->dot_part) mgs_hip_free(c->dot_part);
   if (c->red_host) hipHostFree(c->red_host);
   if (c->own_stream) hipStreamDestroy(c->stream);
   if (c->comm_stream) hipStreamDestroy(c->comm_stream);
@@ -225,7 +221,7 @@ int mgs_ctx_trim(mgs_ctx *ctx) {
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (mgs_vec *v : ctx->ws_free) mgs_vec_destroy(v);
   ctx->ws_free.clear();
-  if (ctx->dot_part) { hipFree(ctx->dot_part); ctx->dot_part = nullptr; ctx->dot_part_cap = 0; }
+  if (ctx->dot_part) { mgs_hip_free(ctx->dot_part); ctx->dot_part = nullptr; ctx->dot_part_cap = 0; }
   return MGS_OK;
 }
 int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
@@ -341,7 +337,7 @@ int mgs_csr_get_origin(const mgs_csr *A, int *origin) {
 }
 int mgs_csr_set_origin(mgs_csr *A, const int *origin) {
   mgs_ctx *ctx = A->ctx;
-  if (A->origin) { hipFree(A->origin); A->origin = nullptr; }
+  if (A->origin) { mgs_hip_free(A->origin); A->origin = nullptr; }
   if (!origin || A->rows == 0) return MGS_OK;
   MGS_TRY(mgs_dev_alloc(ctx, &A->origin, (size_t)A->rows));
   MGS_HIP(ctx, hipMemcpy(A->origin, origin, sizeof(int) * (size_t)A->rows, hipMemcpyHostToDevice));
@@ -349,9 +345,9 @@ int mgs_csr_set_origin(mgs_csr *A, const int *origin) {
 }
 int mgs_csr_destroy(mgs_csr *A) {
   if (!A) return MGS_OK;
-  if (A->owns) { if (A->rowptr) hipFree(A->rowptr); if (A->col) hipFree(A->col); if (A->val) hipFree(A->val); }
-  if (A->blkptr) hipFree(A->blkptr);
-  if (A->origin) hipFree(A->origin);
+  if (A->owns) { if (A->rowptr) mgs_hip_free(A->rowptr); if (A->col) mgs_hip_free(A->col); if (A->val) mgs_hip_free(A->val); }
+  if (A->blkptr) mgs_hip_free(A->blkptr);
+  if (A->origin) mgs_hip_free(A->origin);
   mgs_free_rowcode(A->code);
   delete A;
   return MGS_OK;
@@ -390,7 +386,7 @@ int mgs_vec_wrap(mgs_ctx *ctx, void *p, int64_t n, mgs_vec **out) {
   *out = v;
   return MGS_OK;
 }
-int mgs_vec_destroy(mgs_vec *v) { if (!v) return MGS_OK; if (v->owns && v->d) hipFree(v->d); delete v; return MGS_OK; }
+int mgs_vec_destroy(mgs_vec *v) { if (!v) return MGS_OK; if (v->owns && v->d) mgs_hip_free(v->d); delete v; return MGS_OK; }
 int mgs_vec_upload(mgs_vec *v, const double *host, int64_t n) {
   MGS_CHECK(v->ctx, n <= v->n, MGS_ERR_INVALID, "mgs_vec_upload: %lld > size %lld", (long long)n, (long long)v->n);
   MGS_HIP(v->ctx, hipMemcpyAsync(v->d, host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, v->ctx->stream));
@@ -440,7 +436,7 @@ int mgs_jacobi(const mgs_csr *A, const mgs_vec *dinv, double omega, const mgs_ve
 int mgs_xfer_create(const mgs_csr *P, mgs_xfer **out) { return k_xfer_from_csr(P, out); }
 int mgs_xfer_destroy(mgs_xfer *T) {
   if (!T) return MGS_OK;
-  if (T->agg) hipFree(T->agg); if (T->cptr) hipFree(T->cptr); if (T->members) hipFree(T->members); if (T->corigin) hipFree(T->corigin); if (T->halo_cmap) hipFree(T->halo_cmap);
+  if (T->agg) mgs_hip_free(T->agg); if (T->cptr) mgs_hip_free(T->cptr); if (T->members) mgs_hip_free(T->members); if (T->corigin) mgs_hip_free(T->corigin); if (T->halo_cmap) mgs_hip_free(T->halo_cmap);
   if (T->P) mgs_csr_destroy(T->P); if (T->Pt) mgs_csr_destroy(T->Pt);
   delete T;
   return MGS_OK;
@@ -518,19 +514,19 @@ static void level_free(mgs_level &L) {
   if (L.T) mgs_xfer_destroy(L.T);
   mgs_vec_destroy(L.dinv); mgs_vec_destroy(L.r); mgs_vec_destroy(L.tmp); mgs_vec_destroy(L.b); mgs_vec_destroy(L.x); mgs_vec_destroy(L.wd);
   mgs_vec_destroy(L.hbuf);
-  if (L.val_wd) hipFree(L.val_wd);
-  if (L.col_agg) hipFree(L.col_agg);
-  if (L.cmap_ext) hipFree(L.cmap_ext);
+  if (L.val_wd) mgs_hip_free(L.val_wd);
+  if (L.col_agg) mgs_hip_free(L.col_agg);
+  if (L.cmap_ext) mgs_hip_free(L.cmap_ext);
   mgs_free_rowcode(L.code_agg);
   if (L.AP) mgs_csr_destroy(L.AP);
   mgs_free_rowcode(L.code_ap);
   mgs_free_rowcode(L.code_pre);
   mgs_free_rowcode(L.code_hat);
   mgs_free_groups(L.grp);
-  if (L.dpos) hipFree(L.dpos);
-  if (L.nx) { if (L.nx->send_idx) hipFree(L.nx->send_idx); if (L.nx->sendbuf) hipFree(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
+  if (L.dpos) mgs_hip_free(L.dpos);
+  if (L.nx) { if (L.nx->send_idx) mgs_hip_free(L.nx->send_idx); if (L.nx->sendbuf) mgs_hip_free(L.nx->sendbuf); delete L.nx; L.nx = nullptr; }
   mgs_vec_destroy(L.kc1); mgs_vec_destroy(L.kv1); mgs_vec_destroy(L.kc2); mgs_vec_destroy(L.kv2); mgs_vec_destroy(L.kr);
-  if (L.kscal) hipFree(L.kscal);
+  if (L.kscal) mgs_hip_free(L.kscal);
   L = mgs_level();
 }
 static void drop_graph(mgs_hier *h) {
@@ -554,7 +550,7 @@ int mgs_hier_create(mgs_ctx *ctx, const mgs_csr *A, double omega, int nu1, int n
 static void free_native_tail(mgs_hier *h) {
   mgs_native_tail *T = h->ntail;
   if (!T) return;
-  if (T->send) hipFree(T->send); if (T->all) hipFree(T->all); if (T->gidx) hipFree(T->gidx); if (T->halo_global) hipFree(T->halo_global);
+  if (T->send) mgs_hip_free(T->send); if (T->all) mgs_hip_free(T->all); if (T->gidx) mgs_hip_free(T->gidx); if (T->halo_global) mgs_hip_free(T->halo_global);
   mgs_vec_destroy(T->b); mgs_vec_destroy(T->x);
   delete T; h->ntail = nullptr;
 }
@@ -564,7 +560,7 @@ int mgs_hier_destroy(mgs_hier *h) {
   drop_graph(h);
   for (hipEvent_t e : h->fork_events) hipEventDestroy(e);
   for (auto &L : h->lev) level_free(L);
-  if (h->inv) hipFree(h->inv);
+  if (h->inv) mgs_hip_free(h->inv);
   free_native_tail(h);
   delete h;
   return MGS_OK;
@@ -579,7 +575,7 @@ int mgs_hier_set_native_exchange(mgs_hier *h, int level, mgs_comm *c, const int 
   mgs_ctx *ctx = h->ctx;
   MGS_CHECK(ctx, level >= 0 && level < (int)h->lev.size(), MGS_ERR_INVALID, "mgs_hier_set_native_exchange: level %d out of range", level);
   mgs_level &L = h->lev[level];
-  auto free_plan = [](mgs_native_plan *P) { if (!P) return; if (P->send_idx) hipFree(P->send_idx); if (P->sendbuf) hipFree(P->sendbuf); delete P; };
+  auto free_plan = [](mgs_native_plan *P) { if (!P) return; if (P->send_idx) mgs_hip_free(P->send_idx); if (P->sendbuf) mgs_hip_free(P->sendbuf); delete P; };
   free_plan(L.nx); L.nx = nullptr;
   drop_graph(h);
   h->native = false; for (auto &q : h->lev) h->native = h->native || q.nx;
@@ -697,7 +693,7 @@ int mgs_hier_set_native_tail_halo(mgs_hier *h, const int *halo_global, int n) {
   mgs_native_tail *T = h->ntail;
   hipStreamSynchronize(ctx->stream);
   drop_graph(h);
-  if (T->halo_global) { hipFree(T->halo_global); T->halo_global = nullptr; T->n_halo_global = 0; }
+  if (T->halo_global) { mgs_hip_free(T->halo_global); T->halo_global = nullptr; T->n_halo_global = 0; }
   if (n <= 0 || !halo_global) return MGS_OK;
   const mgs_csr *Al = h->lev.back().A;
   MGS_CHECK(ctx, n == Al->cols - Al->rows, MGS_ERR_INVALID, "mgs_hier_set_native_tail_halo: %d rows given, the last sharded level has %d halo slots", n, Al->cols - Al->rows);
@@ -748,7 +744,7 @@ static int push_level(mgs_hier *h, mgs_xfer *T, mgs_csr *Ac) {
   h->lev.emplace_back();
   int rc = level_init(h, h->lev.back(), Ac, true);
   h->finalized = false; drop_graph(h);
-  if (h->inv) { hipFree(h->inv); h->inv = nullptr; }
+  if (h->inv) { mgs_hip_free(h->inv); h->inv = nullptr; }
   return rc;
 }
 
@@ -775,11 +771,11 @@ int mgs_aggregate_shard_zoned(const mgs_csr *A, double ktg, int npass, double to
   int *dz = nullptr;
   if (zone && A->rows) {
     MGS_TRY(mgs_dev_alloc(ctx, &dz, (size_t)A->rows));
-    if (hipMemcpy(dz, zone, sizeof(int) * (size_t)A->rows, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dz); return mgs_fail(ctx, MGS_ERR_HIP, "mgs_aggregate_shard_zoned: upload failed"); }
+    if (hipMemcpy(dz, zone, sizeof(int) * (size_t)A->rows, hipMemcpyHostToDevice) != hipSuccess) { mgs_hip_free(dz); return mgs_fail(ctx, MGS_ERR_HIP, "mgs_aggregate_shard_zoned: upload failed"); }
   }
   const int rc = k_pairwise_aggregate(A, ktg, npass, tou, T, &Ac, dz);
   hipStreamSynchronize(ctx->stream);
-  if (dz) hipFree(dz);
+  if (dz) mgs_hip_free(dz);
   if (Ac) mgs_csr_destroy(Ac);
   return rc;
 }
@@ -796,10 +792,10 @@ int mgs_galerkin_shard(const mgs_csr *A, const mgs_xfer *T, const int *halo_coar
   MGS_HIP(ctx, hipMemcpyAsync(d, halo_coarse_col, sizeof(int) * (size_t)n_halo, hipMemcpyHostToDevice, ctx->stream));
   int rc = k_galerkin_agg_ext(A, T, d, n_halo_coarse, Ac);
   hipStreamSynchronize(ctx->stream);
-  if (rc != MGS_OK) { hipFree(d); return rc; }
+  if (rc != MGS_OK) { mgs_hip_free(d); return rc; }
   // the map stays with the transfer: the fused post pass runs on A·P whose halo columns are the coarse level's own halo columns
   mgs_xfer *Tm = const_cast<mgs_xfer *>(T);
-  if (Tm->halo_cmap) hipFree(Tm->halo_cmap);
+  if (Tm->halo_cmap) mgs_hip_free(Tm->halo_cmap);
   Tm->halo_cmap = d; Tm->n_halo_fine = n_halo; Tm->n_halo_coarse = n_halo_coarse;
   return MGS_OK;
 }
@@ -831,7 +827,7 @@ int mgs_hier_finalize(mgs_hier *h) {
   mgs_ctx *ctx = h->ctx;
   const mgs_csr *Ac = h->lev.back().A;
   MGS_CHECK(ctx, Ac->rows == Ac->cols, MGS_ERR_STATE, "coarsest operator is not square");
-  if (h->inv) { hipFree(h->inv); h->inv = nullptr; }
+  if (h->inv) { mgs_hip_free(h->inv); h->inv = nullptr; }
   h->nc = Ac->rows;
   h->coarse_sweeps = 0;
   if (Ac->rows > 8192) {

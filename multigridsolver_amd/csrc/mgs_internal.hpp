@@ -255,14 +255,12 @@ struct mgs_hier {
 };
 
 // ------------------------------------------------------------------ device memory arena (mgs_api.hip)
-// Every device allocation of the library goes through these two.  With an arena (MGS_ARENA_GB = N, or mgs_arena_reserve) the library takes
+// Every device allocation of the library goes through these two (never hipMalloc / hipFree directly: tests/test_abi.py greps for it).  With an arena (MGS_ARENA_GB = N, or mgs_arena_reserve) the library takes
 // ONE hipMalloc of N GiB at its first allocation and places operators and vectors inside it (first fit, lowest address first, 2 MiB
 // alignment for anything of 1 MiB or more, blocks coalesced on release); requests that do not fit fall through to hipMalloc.  Without
 // one (default) they are hipMalloc / hipFree.  Why: DESIGN.md §5 "process to process".
 hipError_t mgs_hip_malloc(void **p, size_t bytes);
 hipError_t mgs_hip_free(void *p);
-#define hipMalloc(p, n) mgs_hip_malloc((void **)(p), (n))
-#define hipFree(p) mgs_hip_free((void *)(p))
 
 // ------------------------------------------------------------------ error plumbing
 extern thread_local std::string g_mgs_last_error;
@@ -362,7 +360,7 @@ int mgs_csr_alloc(mgs_ctx *ctx, int rows, int cols, int64_t nnz, mgs_csr **out);
 template <class T>
 static inline int mgs_dev_alloc(mgs_ctx *ctx, T **p, size_t count) {
   *p = nullptr;
-  hipError_t e = hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
+  hipError_t e = mgs_hip_malloc((void **)p, sizeof(T) * (count ? count : 1));
   if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_ALLOC, "hipMalloc(%zu bytes): %s", sizeof(T) * count, hipGetErrorString(e));
   return MGS_OK;
 }

@@ -74,7 +74,7 @@ int scan_rec(mgs_ctx *ctx, const int *in, int *out, int64_t n) {
     if (e != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "scan launch: %s", hipGetErrorString(e));
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(sums);
+  mgs_hip_free(sums);
   return rc;
 }
 
@@ -367,7 +367,7 @@ __global__ void agg_compose_kernel(int n, int *__restrict__ agg, const int *__re
 
 struct DevBuf {  // RAII for setup temporaries
   void *p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
+  ~DevBuf() { if (p) mgs_hip_free(p); }
   template <class T> T *as() { return (T *)p; }
 };
 template <class T>
@@ -409,7 +409,7 @@ int k_xfer_from_agg_host(mgs_ctx *ctx, int n_fine, int n_coarse, const int *agg_
   int *agg = nullptr;
   MGS_TRY(mgs_dev_alloc(ctx, &agg, (size_t)n_fine));
   for (int i = 0; i < n_fine; ++i)
-    if (agg_host[i] < -1 || agg_host[i] >= n_coarse) { hipFree(agg); return mgs_fail(ctx, MGS_ERR_INVALID, "aggregate id %d of row %d outside [-1,%d)", agg_host[i], i, n_coarse); }
+    if (agg_host[i] < -1 || agg_host[i] >= n_coarse) { mgs_hip_free(agg); return mgs_fail(ctx, MGS_ERR_INVALID, "aggregate id %d of row %d outside [-1,%d)", agg_host[i], i, n_coarse); }
   MGS_HIP(ctx, hipMemcpyAsync(agg, agg_host, sizeof(int) * (size_t)n_fine, hipMemcpyHostToDevice, ctx->stream));
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return xfer_from_agg(ctx, n_fine, n_coarse, agg, out);
@@ -458,7 +458,7 @@ int k_xfer_from_csr(const mgs_csr *P, mgs_xfer **out) {
   MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hbad == 0) return xfer_from_agg(ctx, P->rows, P->cols, agg, out);
   // general P: keep P and materialise Pᵀ (bicg.cpp:32)
-  hipFree(agg);
+  mgs_hip_free(agg);
   mgs_xfer *T = new mgs_xfer();
   T->ctx = ctx; T->n_fine = P->rows; T->n_coarse = P->cols; T->aggregation = false; T->nnz = P->nnz;
   int rc = mgs_csr_alloc(ctx, P->rows, P->cols, P->nnz, &T->P);
@@ -671,11 +671,11 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     if (rc != MGS_OK) break;
     int *org2 = nullptr;
     rc = origin_of(Abar->rows, agg2, T->corigin, nc2, &org2);
-    if (rc != MGS_OK) { hipFree(agg2); if (org2) hipFree(org2); break; }
+    if (rc != MGS_OK) { mgs_hip_free(agg2); if (org2) mgs_hip_free(org2); break; }
     // compose fine→pair→pair-of-pairs (AGMG.cpp:247-263) and rebuild member lists
     int *aggc = nullptr;
     rc = mgs_dev_alloc(ctx, &aggc, (size_t)n);
-    if (rc != MGS_OK) { hipFree(agg2); hipFree(org2); break; }
+    if (rc != MGS_OK) { mgs_hip_free(agg2); mgs_hip_free(org2); break; }
     hipMemcpyAsync(aggc, T->agg, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
     hipLaunchKernelGGL(agg_compose_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, aggc, agg2);
     mgs_xfer *T2 = nullptr, *Tn = nullptr;
@@ -684,15 +684,15 @@ int k_pairwise_aggregate(const mgs_csr *A, double ktg, int npass, double tou, mg
     (void)n_halo;
     if (rc == MGS_OK) rc = k_galerkin_agg(Abar, T2, &Anew);          // (P1 P2)ᵀ A (P1 P2) = P2ᵀ A_bar P2
     if (T2) mgs_xfer_destroy(T2);
-    if (rc == MGS_OK) rc = xfer_from_agg(ctx, n, nc2, aggc, &Tn); else hipFree(aggc);
-    if (rc != MGS_OK) { if (Anew) mgs_csr_destroy(Anew); hipFree(org2); break; }
+    if (rc == MGS_OK) rc = xfer_from_agg(ctx, n, nc2, aggc, &Tn); else mgs_hip_free(aggc);
+    if (rc != MGS_OK) { if (Anew) mgs_csr_destroy(Anew); mgs_hip_free(org2); break; }
     Tn->corigin = org2;
     mgs_xfer_destroy(T); T = Tn;
     mgs_csr_destroy(Abar); Abar = Anew;
   }
   if (rc != MGS_OK) { mgs_xfer_destroy(T); mgs_csr_destroy(Abar); return rc; }
   // the coarse operator inherits its rows' origins (tie-breaks of the next level's matching)
-  if (Abar->origin) { hipFree(Abar->origin); Abar->origin = nullptr; }
+  if (Abar->origin) { mgs_hip_free(Abar->origin); Abar->origin = nullptr; }
   rc = mgs_dev_alloc(ctx, &Abar->origin, (size_t)std::max(T->n_coarse, 1));
   if (rc == MGS_OK && hipMemcpyAsync(Abar->origin, T->corigin, sizeof(int) * (size_t)T->n_coarse, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "origin copy failed");
   if (rc == MGS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "origin copy failed");

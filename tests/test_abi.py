@@ -203,3 +203,17 @@ def test_loader_default_threads_on_a_multi_megabyte_file(tmp_path):
     r2 = mg.read_mtx(str(q))
     assert np.array_equal(r2[2], rp) and np.array_equal(r2[3], ci)
     assert np.array_equal(r2[4], np.array([float("%g" % x) for x in v]))
+
+
+def test_device_allocations_go_through_the_arena_entry_points():
+    """every device allocation / release of the library is mgs_hip_malloc / mgs_hip_free (so an arena — mgs_arena_reserve, MGS_ARENA_GB —
+    really holds everything); raw hipMalloc / hipFree appear only inside those two functions"""
+    import glob
+    import re
+    pat = re.compile(r"\bhip(Malloc|Free)\(")
+    raw = {}
+    for f in glob.glob(os.path.join(REPO, "multigridsolver_amd", "csrc", "*.h*")):
+        n = sum(1 for line in open(f) if pat.search(line) and not line.lstrip().startswith("//") and "mgs_fail(" not in line)
+        if n:
+            raw[os.path.basename(f)] = n
+    assert raw == {"mgs_api.hip": 3}, raw
