@@ -526,8 +526,13 @@ class ShardedHierarchy:
             except Exception as e:  # noqa: BLE001
                 ok = False; err = e
             if agree(ok):
-                for l, nseg, lens in self._seg_args:                    # every rank is here: the switch to ranges happens on all of them
-                    check(lib().mgs_hier_set_native_recv_segments(self.h.h, l, nseg.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p)), ctx.h)
+                try:
+                    for l, nseg, lens in self._seg_args:                # every rank is here: the switch to ranges happens on all of them
+                        check(lib().mgs_hier_set_native_recv_segments(self.h.h, l, nseg.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p)), ctx.h)
+                except Exception as e:  # noqa: BLE001
+                    ok = False; err = e
+                if not agree(ok):       # some rank sends ranges, another does not: no way back to a consistent native transport
+                    return fail("installation of the receive ranges", locals().get("err"))
                 self.native_segments = [[len(a) for a in out] for out in segs]
                 if log:
                     log("native exchanges send contiguous row ranges straight from the vectors (ranges per peer and level: "
