@@ -93,12 +93,18 @@ def test_native_transport_multi_rank_matches_oracle(world, N, tail):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_general_operator_matches_oracle(world, inputs):
+@pytest.mark.parametrize("world,native", [(2, 0), (3, 0), (2, 1), (3, 2)])
+def test_sharded_general_operator_matches_oracle(world, native, inputs):
     """a bundled, nonsymmetric operator (CSky3d30) sharded by contiguous row ranges with the generic halo plan
-    (shard_from_global): sharded cycle vs the oracle on the globally assembled hierarchy, sharded solve to 1e-10"""
+    (shard_from_global): sharded cycle vs the oracle on the globally assembled hierarchy, sharded solve to 1e-10.
+    native 1: the native transport on the stand-in RCCL (send lists that are NOT plane ranges: packed or multi-range exchanges,
+    zones over irregular lists, halo of the tail level from the replicated solution); 2: the same, stream-ordered and captured."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    port = 29700 + (os.getpid() % 1000) + world
+    if native:
+        env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so"))
+        if native == 2:
+            env["MGS_FAKE_RCCL_STREAM"] = "1"
+    port = 29700 + (os.getpid() % 1000) + world + 20 * native
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), "0", "3000", "1", "1", inputs["CSky3d30"]]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
