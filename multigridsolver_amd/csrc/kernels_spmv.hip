@@ -376,6 +376,32 @@ constexpr int CODE_NEG = (int)0x80000000;   // table word of a negative index (c
 // slot − row (constant along a plane boundary, where index − base is not): word = CODE_HALO + (slot − row).
 constexpr int CODE_HALO = 0x60000000, CODE_HALO_LO = 0x50000000, CODE_OFF_MAX = 0x40000000;
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3 — the gfx9 scan; lanes without a source take the `old` operand, 0).  Every lane of
+// the wave must be active.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+// Entry range of a row of a CODED block without reading rowptr per row (option rowptr_scan): a pattern id fixes the row's length (the
+// table holds the patterns back to back, ints[0] = their count), so a row starts at rowptr[first row of its wave] — one load per wave —
+// plus the wave's prefix sum of lengths.  4 B per row less to stream.  Called by all lanes, behind the barrier that publishes the table.
+__device__ __forceinline__ void coded_row_range(const int *__restrict__ ints, int tb, int tlen_blk, int mypid, bool valid, int wave_first, int &ga, int &ge) {
+  int len = 0;
+  if (valid) {
+    const int np = ints[tb];
+    const int p0 = ints[tb + mypid], p1 = (mypid + 1 < np) ? ints[tb + mypid + 1] : tlen_blk;
+    len = p1 - p0;
+  }
+  const int incl = wave_incl_scan(len);
+  ga = wave_first + incl - len; ge = wave_first + incl;
+}
+
 // (round 1: the post pass took 68 VGPRs unbounded = 7 waves per SIMD, bounded to 8 waves it measured 2 % faster, the other ops 0.5–0.8 % slower;
 // since its prologue was rewritten it needs 52–56, the other ops 58–64, and the bound no longer binds)
 // VAL: the tuples carry the values as well (`vtab`, option valcode): a coded block then streams no matrix entry at all.
@@ -391,7 +417,7 @@ __device__ __forceinline__ void coded_block_body(
     const double *__restrict__ hv /*row shards: values of the indices >= split*/, int split, const double *__restrict__ vtab,
     const unsigned char *__restrict__ dpos /*t-form post pass: position of a_ii inside the row (NULL: read wd)*/,
     const double *__restrict__ dot_w1, double *__restrict__ dot_part /*SpMV: (y·w1, y·y) partials [2][nblocks] of this launch (NULL: none)*/,
-    int dot_nb, int flags /*kernel-uniform; bit 0: no row is longer than U → the gather step runs once, without a loop; bit 1: loop-free staging (option stage_unroll)*/) {
+    int dot_nb, int flags /*kernel-uniform; bit 0: no row is longer than U → the gather step runs once, without a loop; bit 1: loop-free staging (option stage_unroll); bit 2: option rowptr_scan*/) {
   extern __shared__ double lds_raw[];
   constexpr bool POST = OP == FUSE_POST_MAPPED;
   const int r0 = blk * RB;
@@ -412,8 +438,11 @@ __device__ __forceinline__ void coded_block_body(
   const bool dmode = POST && dpos != nullptr && xin == nullptr;    // ωD⁻¹ from the streamed diagonal entry (same bits as wd = ω·(1/a_ii))
   unsigned dp = 255;
   int mypid = 0;      // the row's pattern id: loaded HERE, with the other per-row loads — behind the barrier it was one more full memory latency in series
+  const bool scan = coded && staged && (flags & 4);      // block-uniform: row ranges from the pattern lengths (coded_row_range)
+  int wave_first = 0;
+  if (scan) wave_first = rowptr[min(r0 + (tid & ~63), n)];
   if (row < r1) {
-    ga = rowptr[row]; ge = rowptr[row + 1];
+    if (!scan) { ga = rowptr[row]; ge = rowptr[row + 1]; }
     if (coded) mypid = pid[row];
     if (OP == MGS_OP_SPMV && dot_part) bi = dot_w1[row];       // fused dots: w1 of this row (bi is free in this op); loaded here, not behind the store
     if (OP != MGS_OP_SPMV) bi = b[row];
@@ -468,6 +497,7 @@ __device__ __forceinline__ void coded_block_body(
       }
     }
     __syncthreads();
+    if (scan) coded_row_range(ints, 0, tlen, mypid, row < r1, wave_first, ga, ge);
     late_loads();
     if (row < r1 && ge > ga) {
       const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
@@ -884,7 +914,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
     double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
-    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts /*bit 0: streaming store of t; bit 1: slice staged by LDS-DMA, no loop*/) {
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts /*bit 0: streaming store of t; bit 1: slice staged by LDS-DMA, no loop; bit 2: option rowptr_scan*/) {
   extern __shared__ double lds_raw[];
   const int g = map_block(bm, blockIdx.x);
   if (g < 0) return;
@@ -915,7 +945,10 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     double bi = 0.0;
     unsigned wm = 0u;
     int mypid = 0;                                                        // loaded with the other per-row loads, not behind the barrier
-    if (row < r1) { ga = rowptr[row]; ge = rowptr[row + 1]; bi = b[row]; wm = wmask[row >> 5]; if (coded) mypid = pid[row]; }
+    const bool scan = coded && staged && (nts & 4);                       // block-uniform (coded_row_range)
+    int wave_first = 0;
+    if (scan) wave_first = rowptr[min(r0 + (tid & ~63), n)];
+    if (row < r1) { if (!scan) { ga = rowptr[row]; ge = rowptr[row + 1]; } bi = b[row]; wm = wmask[row >> 5]; if (coded) mypid = pid[row]; }
     double s = 0.0;
     if (staged) {
       const int nch = (nent + 1) >> 1;
@@ -941,6 +974,7 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
         }
       }
       __syncthreads();
+      if (scan) coded_row_range(ints, 0, tlen, mypid, row < r1, wave_first, ga, ge);
       if (row < r1 && ge > ga) {
         const int my_a = ga - start, my_e = ge - start, lim = nent - 1;
         if (coded) {
@@ -1365,7 +1399,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 #define C_(O, UU, H, V) hipLaunchKernelGGL((csr_rowblock_coded_kernel<O, UU, H, V>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                            c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
                                            (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, bm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
-                                           O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0))
+                                           O == MGS_OP_SPMV ? A->dot_w1 : nullptr, O == MGS_OP_SPMV ? A->dot_part : nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0) | (ctx->opt_rowptr_scan ? 4 : 0))
   // group sweep (views with A->sweep set; plain index codes, no halo): one workgroup per row-block group of the grouped pre pass
   BlockMap gbm; dim3 ggrid(1);
   const bool sweep = A->sweep && !hv && !c->vtab && op == FUSE_POST_MAPPED;
@@ -1373,7 +1407,7 @@ static int launch_coded(const mgs_csr *A, const mgs_rowcode *c, int op, const in
 #define CG_(O, UU) hipLaunchKernelGGL((csr_rowblock_coded_group_kernel<O, UU, false, false>), ggrid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, idx, A->val, \
                                       c->pid, c->tptr, c->tab, x, b, dinv, (O == FUSE_POST_MAPPED && A->dpos) ? A->dpos_omega : omega, xin, agg, out, capv, \
                                       (ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? -capi : capi, gbm, A->blkptr, hv, split, c->vtab, O == FUSE_POST_MAPPED ? A->dpos : nullptr, \
-                                      nullptr, nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0), A->sweep->gdesc)
+                                      nullptr, nullptr, (A->rows + RB - 1) / RB, (A->max_row_len <= UU ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0) | (ctx->opt_rowptr_scan ? 4 : 0), A->sweep->gdesc)
 #define CH_(O, UU) do { if (sweep && O == FUSE_POST_MAPPED) CG_(FUSE_POST_MAPPED, UU); \
                         else if (hv) { if (c->vtab) C_(O, UU, true, true); else C_(O, UU, true, false); } \
                         else { if (c->vtab) C_(O, UU, false, true); else C_(O, UU, false, false); } } while (0)
@@ -1577,7 +1611,7 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
                                       G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
 #define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
-                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, ((ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0))
+                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, ((ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0) | (ctx->opt_rowptr_scan ? 4 : 0))
 #define GU_(UU) do { if (pairs) { if (hv) G2_(UU, true); else G2_(UU, false); } else { if (hv) G_(UU, true); else G_(UU, false); } } while (0)
   if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
 #undef GU_

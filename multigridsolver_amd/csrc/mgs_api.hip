@@ -256,6 +256,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "post_results") ctx->opt_post_results = value;
   else if (k == "blas1_pairs") ctx->opt_blas1_pairs = value;
   else if (k == "stage_unroll") ctx->opt_stage_unroll = value;
+  else if (k == "rowptr_scan") ctx->opt_rowptr_scan = value;
   else if (k == "kcycle_energy") ctx->opt_kcycle_energy = value;
   else if (k == "aggpre_max_rows") ctx->opt_aggpre_max_rows = value;
   else if (k == "emu_split_self") ctx->opt_emu_split_self = value;

@@ -56,6 +56,8 @@ struct mgs_ctx {
                                // pairs 6.34 ms, separate kernels 6.64 ms
   int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
   int opt_post_results = 1;   // inner products reach the host through a mapped buffer + ticket the host polls (no copy engine, no interrupt)
+  int opt_rowptr_scan = 1;    // coded row blocks take a row's entry range from its pattern's length (wave prefix sum, one rowptr load per wave) instead of
+                              // two rowptr loads per row: 4 B per row less to stream (kernels_spmv.hip: coded_row_range)
   int opt_stage_unroll = 1;   // row-block kernels stage their value slice without a loop in front of the barrier (predicated 16-byte loads / LDS-DMA): −4 … −7 % per cycle
   int opt_blas1_pairs = 1;    // ... pairs per lane of those kernels: 1 = one-shot workgroups (0: capped persistent grid, k: k pairs per lane)
   int opt_blas1_vec = 1;      // axpby / axpbypcz / update+dots move 16 B per lane with four loads per stream in flight (same per-element bits)

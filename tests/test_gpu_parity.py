@@ -1110,7 +1110,9 @@ def test_pattern_coded_rows_bit_identical(ctx, mg, orc):
     R = sps.random(3000, n + 3000, density=0.0002, random_state=rng, format="csr"); R.data = rng.standard_normal(R.nnz)
     mixed = sps.bmat([[P, None], [R[:, :n], sps.diags(np.full(3000, 9.0)) + R[:, n:]]], format="csr"); mixed.sort_indices()
     shard = sps.hstack([P[: 20 * N * N], sps.random(20 * N * N, 500, density=0.001, random_state=rng)], format="csr"); shard.sort_indices()
-    for name, M in (("regular", P), ("mixed", mixed), ("shard", shard)):
+    keep = sps.diags((np.arange(n - 37) % 7 != 3).astype(np.float64))
+    gaps = (keep @ P[: n - 37]).tocsr(); gaps.eliminate_zeros(); gaps.sort_indices()      # empty rows, a last row block of 219 rows, cols > rows
+    for name, M in (("regular", P), ("mixed", mixed), ("shard", shard), ("gaps", gaps)):
         Ao = orc.Csr.from_scipy(M.tocsr()); A = dev(ctx, Ao)
         m, k = M.shape
         x_np = rng.standard_normal(k); b_np = rng.standard_normal(m); x = ctx.vec(x_np); b = ctx.vec(b_np)
@@ -1127,6 +1129,14 @@ def test_pattern_coded_rows_bit_identical(ctx, mg, orc):
         y1 = A.spmv(x).numpy(); r1 = A.residual(x, b).numpy()
         assert np.array_equal(y0, y1) and np.array_equal(r0, r1), name
         assert np.array_equal(y1, Ao.spmv(x_np)) and np.array_equal(r1, Ao.residual(x_np, b_np)), name
+        ctx.set_option("rowptr_scan", 0)        # row ranges from rowptr instead of the patterns' lengths: the same entries
+        try:
+            y2 = A.spmv(x).numpy(); r2 = A.residual(x, b).numpy()
+        finally:
+            ctx.set_option("rowptr_scan", 1)
+        assert np.array_equal(y2, y1) and np.array_equal(r2, r1), name
+        if name == "gaps":
+            assert info["coded_blocks"] > 0, info
         if m == k:
             dinv = A.diag_inv()
             assert np.array_equal(A.jacobi(dinv, 0.7, b, x).numpy(), Ao.jacobi(Ao.diag_inv(), 0.7, b_np, x_np)), name
@@ -1142,6 +1152,12 @@ def test_pattern_coded_rows_bit_identical(ctx, mg, orc):
         ctx.set_option("rowcode", 1)
     assert np.array_equal(y0, y1)
     assert h.level_A(0).rowcode_info()["coded_blocks"] > 0
+    ctx.set_option("rowptr_scan", 0)
+    try:
+        y2 = h.vcycle(b).numpy()
+    finally:
+        ctx.set_option("rowptr_scan", 1)
+    assert np.array_equal(y2, y1)
 
 
 def test_value_pattern_coding_bit_identical(ctx, mg, orc):
