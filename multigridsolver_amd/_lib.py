@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libmgs.so")
+SO_PATH = os.environ.get("MGS_LIBMGS") or os.path.join(HERE, "libmgs.so")      # MGS_LIBMGS: another build of the same ABI (A/B runs of tools/ab_lib.sh)
 
 c_int_p = C.POINTER(C.c_int)
 c_dbl_p = C.POINTER(C.c_double)
