@@ -366,7 +366,8 @@ int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements (initial values of every context: environment MGS_OPTIONS="key=value,...").  key: "spmv_variant", "xcd_remap", "nontemporal",
  * "graph", "strip", "fuse", "nt_store" (smallest operator, in rows, whose row-block kernels store their outputs with the `nt` hint; default 1000000,
- * 0 = never), "stage_unroll" (row-block kernels stage their value slice without a loop in front of the barrier; default 1), "blas1_vec" / "blas1_pairs" (16-byte update
+ * 0 = never), "stage_unroll" (row-block kernels stage their value slice without a loop in front of the barrier; default 1), "rowptr_scan" (pattern-coded row blocks take a row's
+ * entry range from its pattern's length — one rowptr load per wave + a wave prefix sum — instead of two rowptr loads per row; default 1, same bits), "blas1_vec" / "blas1_pairs" (16-byte update
  * kernels, pairs per lane: 1 = one-shot workgroups; defaults 1 / 1), "post_results" (inner products reach the host through a mapped buffer and a polled ticket; default 1), "valcode" (opt-in: pattern tuples carry the values too, set before
  * mgs_csr_optimize / the hierarchy is built; pays only where coefficients repeat), "rowcode" (pattern-coded index, default 1), "split_min_rows" (row shards: smallest level that
  * overlaps its halo exchange with interior row blocks, default 400000), "fuse_operands" (setup-time operands of the fused cycle passes,
