@@ -93,7 +93,7 @@ def optin_value_patterns(mg, args, N):
         ms_cycle = h.time_vcycle(b, x, reps=args.steps)
         code = A.rowcode_info()
         out = {"option": "valcode=1 (opt-in, off by default)", "vcycles_per_s": 1e3 / ms_cycle, "ms_per_vcycle": ms_cycle, "spmv_ms": ms_spmv,
-               "spmv_streamed_bytes": 21 * n + 12 * code["table_ints"] + 8 * (code["blocks"] + 1),
+               "spmv_streamed_bytes": 17 * n + n // 16 + 12 * code["table_ints"] + 8 * (code["blocks"] + 1),
                "coded_row_blocks": code["coded_blocks"], "row_blocks": code["blocks"],
                "note": "same bits as the default path (tests/test_gpu_parity.py::test_value_pattern_coding_bit_identical); benefits only operators "
                        "whose rows repeat index shape AND values (constant / piecewise-constant coefficients)"}
@@ -355,7 +355,7 @@ def main():
     ctx.set_option("rowcode", 1)
     A.optimize()
     code = A.rowcode_info()
-    streamed = (8 * nnz + 21 * n + 4 * code["table_ints"] + 4 * (code["blocks"] + 1) * 2) if code["coded_blocks"] == code["blocks"] else None
+    streamed = (8 * nnz + 17 * n + n // 16 + 4 * code["table_ints"] + 4 * (code["blocks"] + 1) * 2) if code["coded_blocks"] == code["blocks"] else None
     A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
     ms_spmv = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=args.kernel_reps)
     ms_res = A.time_kernel(mg.OP_RESIDUAL, xs, b=b, out=y, reps=args.kernel_reps)
@@ -442,7 +442,7 @@ def main():
 
     traffic, traffic_src = pmc_traffic("spmv", N) or (None, None)
     # what crosses HBM in one launch of the dominant kernel: the PMC measurement of the committed profile of this build, else the
-    # bytes the kernel streams by construction (8 B per entry + 21 B per row + tables), else the CSR byte count (plain CSR kernel)
+    # bytes the kernel streams by construction (8 B per entry + 17 B per row: x, y, pattern id; rowptr once per wave; tables), else the CSR byte count (plain CSR kernel)
     phys_bytes = traffic or streamed or spmv_bytes(n, nnz)
     phys_basis = (f"PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of {traffic_src} / this run's ms_per_launch" if traffic else
                   ("bytes the kernel streams by construction / this run's ms_per_launch (no committed PMC summary for this grid)" if streamed else

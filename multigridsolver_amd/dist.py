@@ -752,7 +752,7 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
         loc_bytes = spmv_bytes(n_loc, A.nnz)
         g = loc_bytes / (ms_k * 1e-3) / 1e9
         code = A.rowcode_info()
-        streamed = (8 * A.nnz + 21 * n_loc + 4 * code["table_ints"] + 8 * (code["blocks"] + 1)) if code["coded_blocks"] == code["blocks"] else None
+        streamed = (8 * A.nnz + 17 * n_loc + n_loc // 16 + 4 * code["table_ints"] + 8 * (code["blocks"] + 1)) if code["coded_blocks"] == code["blocks"] else None
         # HBM traffic of the shard's launch: the committed PMC measurement of the full-grid launch (same kernel, same bytes
         # per row) scaled by this shard's share of the rows — counters cannot be read inside a multi-process run
         tr = pmc_traffic("spmv", N) if pmc_traffic else None
