@@ -123,12 +123,16 @@ def main():
     assert err <= 1e-10, err
     # K-cycle on the sharded levels: inner products summed over the ranks, against the oracle's K-cycle
     kerr = None
+    # (tolerance: the K-cycle's coefficients are quotients of inner products whose summation order differs between device, shards and oracle; on
+    # large grids the second direction is nearly parallel to the first and that rounding is amplified — the UNSHARDED device K-cycle differs from the
+    # oracle's by 7e-9 … 3e-8 at 128³, `tools/kcycle_diag_gpu.py 128` — so 1e-9 holds for the small grids only)
+    ktol = 1e-9 if N <= 48 else 1e-7
     if len(sh.plans) >= 3 and not mtx:
         sh.set_kcycle(1); ho.set_kcycle(1)
         xk = ctx.vec(n_ext); sh.vcycle(b, xk)
         xkr = ho.vcycle(bg)
         kerr = np.linalg.norm(xk.numpy(n_loc) - xkr[lo * n2: hi * n2]) / np.linalg.norm(xkr[lo * n2: hi * n2])
-        assert kerr <= 1e-9, kerr
+        assert kerr <= ktol, kerr
         assert np.linalg.norm(xk.numpy(n_loc) - x_loc) > 1e-6 * np.linalg.norm(x_loc), "K-cycle did not change the cycle"
         # K levels reaching past the last sharded level: that level (the replicated tail's entry level) gets its two Krylov steps too
         kdeep = len(sh.plans) + 1
@@ -136,7 +140,7 @@ def main():
         xk2 = ctx.vec(n_ext); sh.vcycle(b, xk2)
         xk2r = ho.vcycle(bg)
         kerr2 = np.linalg.norm(xk2.numpy(n_loc) - xk2r[lo * n2: hi * n2]) / np.linalg.norm(xk2r[lo * n2: hi * n2])
-        assert kerr2 <= 1e-9, ("K-cycle through the replicated tail", kerr2)
+        assert kerr2 <= ktol, ("K-cycle through the replicated tail", kerr2)
         sh.set_kcycle(0); ho.set_kcycle(0)
     # preconditioned solve across shards (dots all-reduced), true residual checked globally
     xsol = ctx.vec(n_ext)

@@ -14,9 +14,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,N,tail,overlap,fused", [(2, 20, 1500, 1, 1), (3, 18, 800, 1, 1), (2, 40, 3000, 1, 1), (2, 20, 1500, 0, 1),
-                                                        (2, 20, 1500, 1, 0), (3, 18, 800, 0, 0), (4, 24, 1200, 1, 1)])
+                                                        (2, 20, 1500, 1, 0), (3, 18, 800, 0, 0), (4, 24, 1200, 1, 1),
+                                                        (4, 128, 40000, 1, 1)])      # 524 288 rows per rank: the product's own thresholds pick the forms
 def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
+    """callback transport (torch.distributed / gloo, halo buffers staged through the host), 2-4 ranks on this one GPU, against the oracle's cycle on
+    the globally assembled hierarchy; the worker also checks Galerkin products, K-cycles and a solve to 1e-10"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if N >= 100:
+        env["MGS_OPTIONS"] = "split_min_rows=400000"      # the worker leaves the interior/boundary split threshold alone when the option is given
     port = 29600 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), str(overlap), str(fused)]
@@ -56,7 +61,10 @@ def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
 
 
 @pytest.mark.parametrize("world,N,tail,opts", [(2, 20, 1500, ""), (3, 18, 800, ""), (2, 40, 3000, ""), (4, 18, 600, ""),
-                                                  (2, 40, 3000, "group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000"), (2, 40, 700, "")])
+                                                  (2, 40, 3000, "group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000"), (2, 40, 700, ""),
+                                                  # 128³ on four ranks (524 288 rows each): the thresholds of the product decide the forms, as in the N-GPU run —
+                                                  # grouped pre pass with halo columns, strip-major block map, pack-free range sends, zoned shard aggregation
+                                                  (4, 128, 40000, "split_min_rows=400000")])
 def test_native_cycle_captured_in_a_graph_multi_rank(world, N, tail, opts):
     """The DEFAULT multi-GPU path — native transport with the whole cycle (exchanges, tail all-gather, tail cycle, K-cycle scalars
     summed over the ranks) captured in one hipGraph — with several ranks on this one GPU: tests/fake_rccl in its stream-ordered mode
