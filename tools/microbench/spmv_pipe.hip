@@ -186,6 +186,28 @@ __global__ __launch_bounds__(RB) void spmv_glds(const double *__restrict__ val, 
   }
 }
 
+// R2: two row blocks per workgroup, every lane owns row t of both: one barrier per 512 rows, the 14 gathers of a lane's two rows in flight together
+__global__ __launch_bounds__(RB) void spmv_two(const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, long n, int N) {
+  __shared__ double vals[2 * SLICE];
+  const int tid = threadIdx.x;
+  const long N2 = (long)N * N, r0 = (long)blockIdx.x * 2 * RB;
+  if (r0 >= n) return;
+  const double *src = val + r0 * NZ;
+#pragma unroll 7
+  for (int c = tid; c < SLICE; c += RB) *reinterpret_cast<double2_t *>(vals + 2 * c) = *reinterpret_cast<const double2_t *>(src + 2 * c);
+  __syncthreads();
+  const long off[NZ] = {-N2, -N, -1, 0, 1, N, N2};
+  const long ra = r0 + tid, rb = r0 + RB + tid;
+  double xa[NZ], xb[NZ], sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) { long c = ra + off[q]; c = c < 0 ? 0 : (c >= n ? n - 1 : c); xa[q] = x[c]; }
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) { long c = rb + off[q]; c = c < 0 ? 0 : (c >= n ? n - 1 : c); xb[q] = x[c]; }
+#pragma unroll
+  for (int q = 0; q < NZ; ++q) { sa += vals[tid * NZ + q] * xa[q]; sb += vals[SLICE + tid * NZ + q] * xb[q]; }
+  y[ra] = sa; y[rb] = sb;
+}
+
 template <class K>
 void run(const char *name, K kernel, int rows_per_wg, const double *val, const double *x, double *y, long n, int N, int threads = RB) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -230,6 +252,9 @@ int main(int argc, char **argv) {
   run("Z  gathers issued before the barrier", spmv_early, RB, val, x, y, n, N);
   run("A  regs->LDS, 1 block/WG (again)", spmv_reg<1>, RB, val, x, y, n, N);
   run("Z  gathers issued before the barrier (again)", spmv_early, RB, val, x, y, n, N);
+  run("R2 two rows per lane, 512 rows/WG", spmv_two, 2 * RB, val, x, y, n, N);
+  run("A  regs->LDS, 1 block/WG (again)", spmv_reg<1>, RB, val, x, y, n, N);
+  run("R2 two rows per lane (again)", spmv_two, 2 * RB, val, x, y, n, N);
   run("A without the x gather   (64 B/row moved)", spmv_part<1>, RB, val, x, y, n, N);
   run("A without the y store    (64 B/row moved)", spmv_part<2>, RB, val, x, y, n, N);
   run("A without the val stream (16 B/row moved)", spmv_part<3>, RB, val, x, y, n, N);
