@@ -60,7 +60,9 @@ for k in order:
     d["wave cycles parked (WAIT_ANY / WAVE_CYCLES)"] = ratio(g(k, "SQ_WAIT_ANY"), g(k, "SQ_WAVE_CYCLES"))
     d["issue stalls (WAIT_INST_ANY / WAVE_CYCLES)"] = ratio(g(k, "SQ_WAIT_INST_ANY"), g(k, "SQ_WAVE_CYCLES"))
     d["issuing (ACTIVE_INST_ANY / WAVE_CYCLES)"] = ratio(g(k, "SQ_ACTIVE_INST_ANY"), g(k, "SQ_WAVE_CYCLES"))
-    d["mean resident waves per CU (LEVEL_WAVES / BUSY_CU_CYCLES)"] = ratio(g(k, "SQ_LEVEL_WAVES"), g(k, "SQ_BUSY_CU_CYCLES"))
+    # SQ_LEVEL_WAVES reads 0 on this stack; resident waves follow from the cycle sums: WAVE_CYCLES (summed over waves) / BUSY_CU_CYCLES
+    # (summed over SIMDs: a kernel that keeps every slot of a CU full reads 8.0 here, i.e. 8 waves per SIMD = 32 per CU)
+    d["mean resident waves per SIMD, of 8 (WAVE_CYCLES / BUSY_CU_CYCLES)"] = ratio(g(k, "SQ_WAVE_CYCLES"), g(k, "SQ_BUSY_CU_CYCLES"))
     d["mean wave lifetime, quad-cycles (WAVE_CYCLES / WAVES)"] = ratio(g(k, "SQ_WAVE_CYCLES"), g(k, "SQ_WAVES"))
     d["LDS bank-conflict share (BANK_CONFLICT / IDX_ACTIVE)"] = ratio(g(k, "SQ_LDS_BANK_CONFLICT"), g(k, "SQ_LDS_IDX_ACTIVE"))
     d["L2 hit rate (HIT / (HIT + MISS))"] = ratio(g(k, "TCC_HIT_sum"), (g(k, "TCC_HIT_sum") or 0) + (g(k, "TCC_MISS_sum") or 0))
