@@ -339,6 +339,26 @@ int mgs_hier_set_native_tail_halo(mgs_hier *h, const int *halo_global, int n);
 int mgs_hier_native_halo(mgs_hier *h, int level, void *x_dev);
 int mgs_hier_native_send_segments(const mgs_hier *h, int level, int *nseg_per_peer, int *seglens, int cap);
 int mgs_hier_set_native_recv_segments(mgs_hier *h, int level, const int *nseg_per_peer, const int *seglens);
+/* ---- peer-to-peer transport behind the same mgs_comm handle (no reference counterpart) ----
+ * The neighbours store their halo values straight into this rank's memory (IPC-mapped device window, xGMI), one kernel per exchange,
+ * sequence-numbered flag words for ordering — no RCCL kernel, no host round trip; captured in the cycle's hipGraph like any kernel.
+ * Every rank calls mgs_comm_p2p_create (slot_doubles = the most doubles one peer ever sends it in one exchange, all-gather of the tail
+ * included; world <= 8) and gets MGS_P2P_HANDLE_BYTES bytes describing its window; the host side ships those records to all ranks
+ * (rank order) and every rank calls mgs_comm_p2p_connect.  From then on the communicator serves mgs_hier_set_native_exchange /
+ * _tail / mgs_ctx_set_native_allreduce exactly like an RCCL one.  mgs_comm_p2p_info: out[0] memory kind of the window (1 uncached,
+ * 2 fine-grained, 3 coarse-grained), [1] window bytes, [2] slot doubles, [3] exchange kernels launched, [4] error word (0 = none;
+ * 1 + k: the wait for the k-th participating peer of some exchange timed out, MGS_P2P_TIMEOUT_S), [5] connected. */
+#define MGS_P2P_HANDLE_BYTES 96
+int mgs_comm_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void *handle_out, mgs_comm **out);
+int mgs_comm_p2p_connect(mgs_comm *c, const void *handles);
+int mgs_comm_p2p_info(const mgs_comm *c, long long out[6]);
+/* raw operations of a communicator (either transport) on the context's stream — transport tests and microbenchmarks; the cycle uses
+ * them internally.  exchange: one group of sends (send_dev[q] != NULL) and receives (recv_dev[q] != NULL) of count[q] doubles with
+ * rank peer[q]; the ops addressed to one peer are matched with that peer's ops in posting order.  allgather: count doubles per rank,
+ * rank-major into recv_dev.  allreduce: in-place sum of count doubles (p2p: count <= 64, summed in rank order). */
+int mgs_comm_exchange_raw(mgs_comm *c, int nops, const int *peer, const size_t *count, const void *const *send_dev, void *const *recv_dev);
+int mgs_comm_allgather_raw(mgs_comm *c, const void *send_dev, void *recv_dev, size_t count);
+int mgs_comm_allreduce_raw(mgs_comm *c, void *buf_dev, size_t count);
 /* inner products of the Krylov solvers summed over the ranks with ncclAllReduce on the context's stream (NULL: off;
  * takes precedence over the mgs_ctx_set_allreduce callback) */
 int mgs_ctx_set_native_allreduce(mgs_ctx *ctx, mgs_comm *c);

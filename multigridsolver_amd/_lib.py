@@ -19,6 +19,7 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 COARSE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 HALO_FUSED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_dbl_p, C.c_int)
+P2P_HANDLE_BYTES = 96          # MGS_P2P_HANDLE_BYTES
 
 # name -> (restype, argtypes); every symbol declared in include/mgs.h
 PROTOTYPES = {
@@ -41,6 +42,12 @@ PROTOTYPES = {
     "mgs_comm_unique_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "mgs_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mgs_comm_destroy": (C.c_int, [C.c_void_p]),
+    "mgs_comm_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mgs_comm_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgs_comm_p2p_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgs_comm_exchange_raw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgs_comm_allgather_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mgs_comm_allreduce_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mgs_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgs_hier_set_native_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_hier_set_native_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -16,6 +16,7 @@
 
 struct mgs_comm {
   mgs_ctx *ctx = nullptr;
+  mgs_p2p *p2p = nullptr;     // peer-to-peer transport (comm_p2p.hip): the three operations below go through it, RCCL is not loaded
   void *dl = nullptr;
   ncclComm_t comm = nullptr;
   int world = 0, rank = 0;
@@ -86,10 +87,43 @@ int mgs_comm_create(mgs_ctx *ctx, const char *librccl, const void *id_in, int wo
 
 int mgs_comm_destroy(mgs_comm *c) {
   if (!c) return MGS_OK;
+  if (c->p2p) { mgs_p2p_destroy(c->p2p); delete c; return MGS_OK; }
   if (c->comm && c->CommDestroy) c->CommDestroy(c->comm);
   delete c;      // the library handle stays open: the process keeps using it
   return MGS_OK;
 }
+
+// ---- peer-to-peer transport behind the same handle (comm_p2p.hip)
+int mgs_comm_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void *handle_out, mgs_comm **out) {
+  MGS_CHECK(ctx, out, MGS_ERR_INVALID, "mgs_comm_p2p_create: NULL output");
+  mgs_comm *c = new mgs_comm();
+  c->ctx = ctx; c->world = world; c->rank = rank; c->capturable = true;
+  const int rc = mgs_p2p_create(ctx, world, rank, slot_doubles, handle_out, &c->p2p);
+  if (rc != MGS_OK) { delete c; return rc; }
+  *out = c;
+  return MGS_OK;
+}
+int mgs_comm_p2p_connect(mgs_comm *c, const void *handles) {
+  MGS_CHECK(c->ctx, c->p2p, MGS_ERR_STATE, "mgs_comm_p2p_connect: not a peer-to-peer communicator");
+  return mgs_p2p_connect(c->p2p, handles);
+}
+int mgs_comm_p2p_info(const mgs_comm *c, long long out[6]) {
+  MGS_CHECK(c->ctx, c->p2p && out, MGS_ERR_STATE, "mgs_comm_p2p_info: not a peer-to-peer communicator");
+  return mgs_p2p_info(c->p2p, out);
+}
+
+// raw operations of a communicator on the context's stream (transport tests and microbenchmarks; the cycle calls the C++ forms below)
+int mgs_comm_exchange_raw(mgs_comm *c, int nops, const int *peer, const size_t *count, const void *const *send_dev, void *const *recv_dev) {
+  MGS_CHECK(c->ctx, nops >= 0 && (nops == 0 || (peer && count && send_dev && recv_dev)), MGS_ERR_INVALID, "mgs_comm_exchange_raw: bad arguments");
+  std::vector<mgs_xfer_op> ops((size_t)nops);
+  for (int q = 0; q < nops; ++q) {
+    MGS_CHECK(c->ctx, (send_dev[q] != nullptr) != (recv_dev[q] != nullptr) || count[q] == 0, MGS_ERR_INVALID, "mgs_comm_exchange_raw: op %d must be a send or a receive", q);
+    ops[(size_t)q] = mgs_xfer_op{(const double *)send_dev[q], (double *)recv_dev[q], count[q], peer[q]};
+  }
+  return mgs_comm_exchange_ops(c, ops.data(), nops);
+}
+int mgs_comm_allgather_raw(mgs_comm *c, const void *send_dev, void *recv_dev, size_t count) { return mgs_comm_allgather(c, (const double *)send_dev, (double *)recv_dev, count); }
+int mgs_comm_allreduce_raw(mgs_comm *c, void *buf_dev, size_t count) { return mgs_comm_allreduce_sum(c, (double *)buf_dev, count); }
 
 int mgs_comm_size(const mgs_comm *c, int *world, int *rank) { if (world) *world = c->world; if (rank) *rank = c->rank; return MGS_OK; }
 
@@ -100,6 +134,7 @@ int mgs_comm_size(const mgs_comm *c, int *world, int *rank) { if (world) *world 
 // contiguous ranges taken straight from the source vector.  Zero counts issue nothing.
 int mgs_comm_exchange_ops(mgs_comm *c, const mgs_xfer_op *ops, int nops) {
   hipStream_t s = c->ctx->stream;
+  if (c->p2p) return mgs_p2p_exchange_ops(c->p2p, s, ops, nops);
   MGS_NCCL(c, c->GroupStart());
   ncclResult_t bad = ncclSuccess;
   for (int q = 0; q < nops && bad == ncclSuccess; ++q) {
@@ -113,10 +148,12 @@ int mgs_comm_exchange_ops(mgs_comm *c, const mgs_xfer_op *ops, int nops) {
   return MGS_OK;
 }
 int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count) {
+  if (c->p2p) return mgs_p2p_allgather(c->p2p, c->ctx->stream, send, recv, count);
   MGS_NCCL(c, c->AllGather(send, recv, count, ncclDouble, c->comm, c->ctx->stream));
   return MGS_OK;
 }
 int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count) {
+  if (c->p2p) return mgs_p2p_allreduce_sum(c->p2p, c->ctx->stream, buf, count);
   MGS_NCCL(c, c->AllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->ctx->stream));
   return MGS_OK;
 }

@@ -380,24 +380,132 @@ __global__ __launch_bounds__(TB) void dot_block_vec_kernel(int64_t n, const doub
   }
 }
 
+// ------------------------------------------------------------------ several inner products against one vector, one pass
+// s_k = Σ a_i·b_k[i], k < K ≤ MDOT_MAX: `a` is read once.  Partials [K][gridDim.x] in a fixed order (no atomics), folded by
+// mdot_final_kernel — the K-cycle's (ρ1, α1) and the flexible Krylov methods' orthogonalisation coefficients.
+constexpr int MDOT_MAX = 16;
+struct MDotVecs { const double *b[MDOT_MAX]; };
+__global__ __launch_bounds__(TB) void mdot_partial_kernel(int64_t n, int K, const double *__restrict__ a, const MDotVecs B, double *__restrict__ part) {
+  __shared__ double sh[MDOT_MAX][TB / 64];
+  double s[MDOT_MAX];
+#pragma unroll
+  for (int k = 0; k < MDOT_MAX; ++k) s[k] = 0.0;
+  const int64_t n2 = n >> 1, stride = (int64_t)gridDim.x * TB;
+  const vd2 *__restrict__ av = reinterpret_cast<const vd2 *>(a);
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+    const vd2 ai = av[i];
+#pragma unroll
+    for (int k = 0; k < MDOT_MAX; ++k)
+      if (k < K) { const vd2 bi = reinterpret_cast<const vd2 *>(B.b[k])[i]; s[k] += ai.x * bi.x; s[k] += ai.y * bi.y; }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < MDOT_MAX; ++k) if (k < K) s[k] += a[n - 1] * B.b[k][n - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < MDOT_MAX; ++k) {
+    if (k < K) {
+      double t = s[k];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+      if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    double t = 0.0;
+    for (int q = 0; q < TB / 64; ++q) t += sh[threadIdx.x][q];
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+  }
+}
+// fold of K partial arrays of nb entries each (one workgroup, fixed order); out (device) and, with pa.hv, the host's mapped buffer
+__global__ __launch_bounds__(TB) void mdot_final_kernel(int nb, int K, const double *__restrict__ part, double *__restrict__ out, Post pa) {
+  __shared__ double sh[TB];
+  __shared__ double res[MDOT_MAX + 4];
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += TB) s += part[(size_t)k * nb + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = TB / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) { res[k] = sh[0]; if (out) out[k] = sh[0]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && pa.hv) post_to_host(pa, res, K);
+}
+
+// z = x − Σ_{j<K} coef_j·w_j (coefficients by value: they come from the host, which needed them for its own bookkeeping), with
+// (z·z, z·u) accumulated in the same pass (u = NULL: second sum stays 0) — the orthogonalisation update of the flexible Krylov
+// methods: the new direction against the window, its norm and its product with the residual, one read of every vector.
+struct MAxpyArgs { const double *w[MDOT_MAX]; double coef[MDOT_MAX]; };
+__global__ __launch_bounds__(TB) void maxpy_dot2_kernel(int64_t n, int K, const double *__restrict__ x, const MAxpyArgs W, double *__restrict__ z,
+                                                        const double *__restrict__ u, const double *__restrict__ u2, double *__restrict__ part) {
+  __shared__ double sh[2][TB / 64];
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * TB;
+  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) {
+    double zi = x[i];
+#pragma unroll
+    for (int k = 0; k < MDOT_MAX; ++k) if (k < K) zi -= W.coef[k] * W.w[k][i];
+    z[i] = zi;
+    s0 += zi * (u2 ? u2[i] : zi);
+    if (u) s1 += zi * u[i];
+  }
+  if (!part) return;                               // plain multi-axpy
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
+  }
+}
+
 // ------------------------------------------------------------------ K-cycle helpers (device-resident scalars)
-// Two GCR steps on the coarse problem (Notay, SISC 34 (2012), K-cycle for nonsymmetric problems): scal =
-// {ρ1 = v1·v1, α1 = v1·r, γ = v2·v1, β = v2·v2, α2 = v2·r'}; no host round trip, graph-capturable.
+// Two Krylov steps on the coarse problem (Notay, SISC 34 (2012), K-cycle; docs/AGMG_For_Convection_Diffusion.pdf §3.1) with the second
+// direction orthogonalised EXPLICITLY: scal = {ρ1 = d1·v1, α1 = d1·r, γ = d2·v1, ρ2 = d2'·v2', α2 = d2'·r'} with g = γ/ρ1,
+// c2' = c2 − g·c1, v2' = v2 − g·v1 and d = v (GCR form) or d = c (energy form).  ρ2 is a sum of products of the orthogonalised vectors,
+// not the difference β − γ²/ρ1 of two nearly equal numbers (round 3: lost up to five digits where c2 is almost parallel to c1).
+// No host round trip, graph-capturable.
 __global__ void kc_update_r_kernel(int n, const double *__restrict__ scal, const double *__restrict__ r, const double *__restrict__ v1, double *__restrict__ rp) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double rho1 = scal[0], a = rho1 != 0.0 ? scal[1] / rho1 : 0.0;
   rp[i] = r[i] - a * v1[i];
 }
+// (ρ2, α2) of the orthogonalised second direction: partial pair per workgroup
+template <bool ENERGY>
+__global__ __launch_bounds__(TB) void kc_orth_dots_kernel(int n, const double *__restrict__ scal, const double *__restrict__ c1, const double *__restrict__ c2,
+                                                          const double *__restrict__ v1, const double *__restrict__ v2, const double *__restrict__ rp,
+                                                          double *__restrict__ part) {
+  __shared__ double sh[2][TB / 64];
+  const double rho1 = scal[0], g = rho1 != 0.0 ? scal[2] / rho1 : 0.0;
+  double s0 = 0.0, s1 = 0.0;
+  const int stride = gridDim.x * TB;
+  for (int i = blockIdx.x * TB + threadIdx.x; i < n; i += stride) {
+    const double v2o = v2[i] - g * v1[i];
+    const double d2o = ENERGY ? c2[i] - g * c1[i] : v2o;
+    s0 += d2o * v2o;
+    s1 += d2o * rp[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < TB / 64; ++q) { t0 += sh[0][q]; t1 += sh[1][q]; }
+    part[blockIdx.x] = t0; part[gridDim.x + blockIdx.x] = t1;
+  }
+}
+// x = (α1/ρ1)·c1 + (α2/ρ2)·(c2 − g·c1)
 __global__ void kc_combine_kernel(int n, const double *__restrict__ scal, const double *__restrict__ c1, const double *__restrict__ c2, double *__restrict__ x) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double rho1 = scal[0], alpha1 = scal[1], gamma = scal[2], beta = scal[3], alpha2 = scal[4];
+  const double rho1 = scal[0], alpha1 = scal[1], gamma = scal[2], rho2 = scal[3], alpha2 = scal[4];
   double k1 = 0.0, k2 = 0.0;
   if (rho1 != 0.0) {
-    const double rho2 = beta - gamma * gamma / rho1;
     k1 = alpha1 / rho1;
-    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= gamma * k2 / rho1; }
+    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= (gamma / rho1) * k2; }
   }
   x[i] = k1 * c1[i] + k2 * c2[i];
 }
@@ -700,12 +808,12 @@ static Post begin_post(mgs_ctx *ctx) {
   const bool posted = ctx->opt_post_results && ctx->red_host_dev && !ctx->ncomm && hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess &&
                       cs == hipStreamCaptureStatusNone;
   if (!posted) return Post{nullptr, nullptr, 0ull};
-  return Post{ctx->red_host_dev, reinterpret_cast<unsigned long long *>(ctx->red_host_dev + 8), ++ctx->red_ticket};
+  return Post{ctx->red_host_dev, reinterpret_cast<unsigned long long *>(ctx->red_host_dev + MGS_RED_VALS), ++ctx->red_ticket};
 }
 // the reduction's last kernel (launched with `pa`) has been enqueued: wait for its results
 static int fetch_results(mgs_ctx *ctx, int cnt, double *out_host, const Post &pa) {
   if (pa.hv) {
-    volatile unsigned long long *tk = reinterpret_cast<volatile unsigned long long *>(ctx->red_host + 8);
+    volatile unsigned long long *tk = reinterpret_cast<volatile unsigned long long *>(ctx->red_host + MGS_RED_VALS);
     const unsigned long long want = pa.ticket;
     MGS_HIP(ctx, hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();
@@ -833,8 +941,68 @@ int k_dot_dev(mgs_ctx *ctx, int64_t n, const double *x, const double *y, double 
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }
+// workgroups of a multi-vector reduction pass: one-shot at small sizes, a few elements per lane at large ones (partials stay short)
+static int mdot_grid(int64_t n) {
+  int64_t nb = (n / 2 + (int64_t)TB * 4 - 1) / ((int64_t)TB * 4);
+  return (int)std::min<int64_t>(std::max<int64_t>(nb, 1), 2048);
+}
+// s_k = a·b_k, k < K ≤ MDOT_MAX: to device scalars (out_dev) and/or, summed over the ranks, to the host (out_host)
+int k_mdot(mgs_ctx *ctx, int64_t n, int K, const double *a, const double *const *b, double *out_dev, double *out_host) {
+  MGS_CHECK(ctx, K >= 1 && K <= MDOT_MAX && K <= MGS_RED_VALS, MGS_ERR_INVALID, "k_mdot: %d inner products (at most %d)", K, MDOT_MAX);
+  MDotVecs B;
+  bool aligned = al16(a);
+  for (int k = 0; k < MDOT_MAX; ++k) { B.b[k] = k < K ? b[k] : a; if (k < K && !al16(b[k])) aligned = false; }
+  const int nb = mdot_grid(n);
+  double *part = ctx->red_dev;        // (the K-cycle's pairs always fit the context's own scratch: nothing is allocated inside a captured cycle)
+  if ((int64_t)K * nb > DOT_BLOCKS) { MGS_TRY(mgs_ensure_dot_part(ctx, (int64_t)K * nb)); part = ctx->dot_part; }
+  double *res = out_dev ? out_dev : ctx->red_dev + DOT_BLOCKS;
+  if (!aligned) {      // operands that do not start on 16 bytes (views into the middle of a vector): K two-vector reductions
+    for (int k = 0; k < K; ++k) MGS_TRY(k_dot_dev(ctx, n, a, b[k], res + k));
+    if (!out_host) return MGS_OK;
+    if (ctx->ncomm) {
+      if (res != ctx->red_dev + DOT_BLOCKS) MGS_HIP(ctx, hipMemcpyAsync(ctx->red_dev + DOT_BLOCKS, res, sizeof(double) * (size_t)K, hipMemcpyDeviceToDevice, ctx->stream));
+      MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, (size_t)K));
+      res = ctx->red_dev + DOT_BLOCKS;
+    }
+    MGS_HIP(ctx, hipMemcpyAsync(ctx->red_host, res, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+    MGS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < K; ++k) out_host[k] = ctx->red_host[k];
+    if (ctx->allreduce && !ctx->ncomm && ctx->allreduce(ctx->allreduce_user, out_host, K)) return mgs_fail(ctx, MGS_ERR_STATE, "allreduce callback failed");
+    return MGS_OK;
+  }
+  hipLaunchKernelGGL(mdot_partial_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, K, a, B, part);
+  const Post pa = out_host ? begin_post(ctx) : Post{nullptr, nullptr, 0ull};
+  hipLaunchKernelGGL(mdot_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, K, part, res, pa);
+  MGS_HIP(ctx, hipGetLastError());
+  if (!out_host) return MGS_OK;
+  if (res != ctx->red_dev + DOT_BLOCKS) MGS_HIP(ctx, hipMemcpyAsync(ctx->red_dev + DOT_BLOCKS, res, sizeof(double) * (size_t)K, hipMemcpyDeviceToDevice, ctx->stream));   // where fetch_results looks
+  if (ctx->ncomm) MGS_TRY(mgs_comm_allreduce_sum(ctx->ncomm, ctx->red_dev + DOT_BLOCKS, (size_t)K));
+  return fetch_results(ctx, K, out_host, pa);
+}
+// z = x − Σ_{j<K} coef_j·w_j with (z·u2 — or z·z when u2 is NULL —, z·u) to the host in the same pass (out_host2 = NULL: no sums, no round trip)
+int k_maxpy_dot2(mgs_ctx *ctx, int64_t n, int K, const double *x, const double *const *w, const double *coef, double *z, const double *u, const double *u2, double *out_host2) {
+  MGS_CHECK(ctx, K >= 0 && K <= MDOT_MAX, MGS_ERR_INVALID, "k_maxpy_dot2: %d terms (at most %d)", K, MDOT_MAX);
+  MAxpyArgs W;
+  for (int k = 0; k < MDOT_MAX; ++k) { W.w[k] = k < K ? w[k] : x; W.coef[k] = k < K ? coef[k] : 0.0; }
+  int64_t nbl = (n + (int64_t)TB * 2 - 1) / ((int64_t)TB * 2);
+  const int nb = (int)std::min<int64_t>(std::max<int64_t>(nbl, 1), 1 << 20);
+  double *part = nullptr;
+  if (out_host2) { part = ctx->red_dev; if (nb > DOT_BLOCKS / 2) { MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nb)); part = ctx->dot_part; } }
+  hipLaunchKernelGGL(maxpy_dot2_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, K, x, W, z, u, u2, part);
+  MGS_HIP(ctx, hipGetLastError());
+  return out_host2 ? k_dot2_finish(ctx, nb, part, out_host2) : MGS_OK;
+}
 int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp) {
   if (n) hipLaunchKernelGGL(kc_update_r_kernel, dim3(mgs_grid(n, TB)), dim3(TB), 0, ctx->stream, n, scal, r, v1, rp);
+  MGS_HIP(ctx, hipGetLastError());
+  return MGS_OK;
+}
+// scal[3] = ρ2, scal[4] = α2 of the explicitly orthogonalised second direction (see kc_orth_dots_kernel)
+int k_kc_orth_dots(mgs_ctx *ctx, int n, bool energy, double *scal, const double *c1, const double *c2, const double *v1, const double *v2, const double *rp) {
+  const int nb = std::max(1, std::min(mgs_grid(n, TB * 4), DOT_BLOCKS / 2));
+  if (energy) hipLaunchKernelGGL(kc_orth_dots_kernel<true>, dim3(nb), dim3(TB), 0, ctx->stream, n, scal, c1, c2, v1, v2, rp, ctx->red_dev);
+  else hipLaunchKernelGGL(kc_orth_dots_kernel<false>, dim3(nb), dim3(TB), 0, ctx->stream, n, scal, c1, c2, v1, v2, rp, ctx->red_dev);
+  hipLaunchKernelGGL(dot2_final_kernel, dim3(1), dim3(TB), 0, ctx->stream, nb, ctx->red_dev, scal + 3, Post{nullptr, nullptr, 0ull});
   MGS_HIP(ctx, hipGetLastError());
   return MGS_OK;
 }

@@ -1437,7 +1437,9 @@ static int strip_map(BlockMap &bm, int D, int S) {
   const int P = (bm.chunk + D - 1) / D;
   const int per_xcd = ((D + S - 1) / S) * P * S;
   const unsigned long long ps = (unsigned long long)P * (unsigned long long)S;
-  if (D <= 0 || S <= 0 || ((unsigned long long)per_xcd + 1) * ps >= (1ull << 32) || ps * (unsigned long long)S >= (1ull << 32)) { bm.D = bm.S = bm.P = 0; return bm.chunk; }
+  // (S < 2: ⌊2³²/1⌋+1 does not fit 32 bits — the multiply-high quotient would be 0 instead of the dividend; a strip of one block is
+  // the plain plane-major order anyway, so the plain XCD-contiguous map serves)
+  if (D <= 0 || S < 2 || ps < 2 || ((unsigned long long)per_xcd + 1) * ps >= (1ull << 32) || ps * (unsigned long long)S >= (1ull << 32)) { bm.D = bm.S = bm.P = 0; return bm.chunk; }
   bm.D = D; bm.S = S; bm.P = P;
   bm.mps = (unsigned)((1ull << 32) / ps) + 1u;
   bm.mS = (unsigned)((1ull << 32) / (unsigned long long)S) + 1u;

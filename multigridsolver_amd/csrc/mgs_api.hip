@@ -13,6 +13,7 @@ thread_local std::string g_mgs_last_error;
 namespace {
 struct Arena {
   char *base = nullptr; size_t cap = 0; bool tried = false;
+  int device = -1;                          // the arena lives on ONE device (the one current when it was taken) and serves only that one
   std::map<size_t, size_t> free_blocks;     // offset → size, address ordered
   std::map<size_t, size_t> used;            // offset → size
   std::mutex m;
@@ -21,6 +22,7 @@ bool arena_take_locked(size_t cap) {
   void *p = nullptr;
   if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return false; }
   g_arena.base = (char *)p; g_arena.cap = cap; g_arena.free_blocks[0] = cap;
+  if (hipGetDevice(&g_arena.device) != hipSuccess) g_arena.device = -1;
   return true;
 }
 void arena_init_locked() {
@@ -32,7 +34,8 @@ void arena_init_locked() {
   if (!arena_take_locked((size_t)(gb * 1024.0) << 20)) fprintf(stderr, "[mgs] arena of %.1f GiB not available: plain hipMalloc\n", gb);
 }
 }  // namespace
-// One arena per process, reserved before the library's first device allocation (else MGS_ARENA_GB decides at that allocation).
+// One arena per process, on the device current at the reservation: a context on another device of the same process allocates with
+// plain hipMalloc (its operators must not land in a peer's memory).  Reserved before the library's first device allocation (else MGS_ARENA_GB decides at that allocation).
 extern "C" int mgs_arena_reserve(size_t bytes) {
   std::lock_guard<std::mutex> lk(g_arena.m);
   if (g_arena.base) return mgs_fail(nullptr, MGS_ERR_STATE, "mgs_arena_reserve: an arena of %zu bytes exists already", g_arena.cap);
@@ -53,7 +56,8 @@ hipError_t mgs_hip_malloc(void **p, size_t bytes) {
   {
     std::lock_guard<std::mutex> lk(g_arena.m);
     arena_init_locked();
-    if (g_arena.base) {
+    int cur = -1;
+    if (g_arena.base && hipGetDevice(&cur) == hipSuccess && cur == g_arena.device) {
       const size_t align = bytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : (size_t)4096;
       const size_t need = (std::max(bytes, (size_t)1) + align - 1) / align * align;
       for (auto it = g_arena.free_blocks.begin(); it != g_arena.free_blocks.end(); ++it) {
@@ -81,7 +85,13 @@ hipError_t mgs_hip_free(void *p) {
       if (u == g_arena.used.end()) return hipErrorInvalidValue;
       size_t bo = off, bs = u->second;
       g_arena.used.erase(u);
-      (void)hipDeviceSynchronize();                       // hipFree's contract: nothing in flight touches the block afterwards
+      {   // hipFree's contract: nothing in flight touches the block afterwards — on the ARENA's device, whatever is current
+        int cur = -1;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && g_arena.device >= 0 && cur != g_arena.device;
+        if (sw) (void)hipSetDevice(g_arena.device);
+        (void)hipDeviceSynchronize();
+        if (sw) (void)hipSetDevice(cur);
+      }
       auto nx = g_arena.free_blocks.lower_bound(bo);
       if (nx != g_arena.free_blocks.end() && nx->first == bo + bs) { bs += nx->second; nx = g_arena.free_blocks.erase(nx); }
       if (nx != g_arena.free_blocks.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == bo) { bo = pv->first; bs += pv->second; g_arena.free_blocks.erase(pv); } }
@@ -177,10 +187,10 @@ int mgs_ctx_create(int device, void *stream, mgs_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   c->red_cap = 4096 + 64;    // DOT_BLOCKS partials + the folded results (kernels_aux.hip)
-  if (mgs_hip_malloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+  if (mgs_hip_malloc((void **)&c->red_dev, sizeof(double) * c->red_cap) != hipSuccess || hipHostMalloc((void **)&c->red_host, sizeof(double) * 2 * MGS_RED_VALS, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     delete c; return mgs_fail(nullptr, MGS_ERR_ALLOC, "context scratch allocation failed");
   }
-  for (int q = 0; q < 16; ++q) c->red_host[q] = 0.0;
+  for (int q = 0; q < 2 * MGS_RED_VALS; ++q) c->red_host[q] = 0.0;
   if (hipHostGetDevicePointer((void **)&c->red_host_dev, c->red_host, 0) != hipSuccess) { c->red_host_dev = nullptr; (void)hipGetLastError(); }
   // MGS_OPTIONS="key=value,key=value": initial option values of every context (A/B runs of whole test suites)
   if (const char *env = getenv("MGS_OPTIONS")) {
@@ -941,8 +951,9 @@ static int cycle_level(mgs_hier *h, int l, const double *b, double *x, bool zero
 // Approximate solve of the level-l problem A_l x = rhs from x = 0 for the level above.  V-cycle: one
 // recursive cycle.  K-cycle (levels 1..kcycle_levels): two GCR steps preconditioned by that cycle
 // (docs/AGMG_For_Convection_Diffusion.pdf §3.1; Fortran `nlvcyc`, src/CPU_Matlab/dagtwolev_mex.f90:59-61):
-//   c1 = B rhs, v1 = A c1, r' = rhs − (α1/ρ1) v1;  c2 = B r', v2 = A c2;
-//   x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1.
+//   c1 = B rhs, v1 = A c1, r' = rhs − (α1/ρ1) v1;  c2 = B r', v2 = A c2, g = γ/ρ1;
+//   x = (α1/ρ1) c1 + (α2/ρ2) (c2 − g c1),  ρ2 and α2 from the explicitly orthogonalised pair (c2 − g c1, v2 − g v1) — the paper's
+//   ρ2 = β − γ²/ρ1 in exact arithmetic, without the difference of two nearly equal numbers.
 static bool kcycle_here(const mgs_hier *h, int l) {
   const bool sharded = h->halo || h->halo_begin || h->native;
   // row shards: the five inner products are summed over the ranks — needs a reduction transport (native RCCL or the callback)
@@ -983,18 +994,20 @@ static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x) 
   MGS_TRY(cycle_level(h, l, rhs, L.kc1->d, true));
   MGS_TRY(sharded_op(h, l, L.A, MGS_OP_SPMV, L.kc1->d, nullptr, nullptr, 0.0, L.kv1->d));      // halo of c1 refreshed on a row shard
   // GCR form (paper §3.1): inner products with v = A·c.  Energy form (option kcycle_energy, SPD operators; flexible-CG coefficients):
-  // the same five products with c as left factor — ρ1 = c1·Ac1, α1 = c1·rhs, γ = c2·Ac1, β = c2·Ac2, α2 = c2·r'; same update formulas.
-  const double *d1 = ctx->opt_kcycle_energy ? L.kc1->d : L.kv1->d, *d2 = ctx->opt_kcycle_energy ? L.kc2->d : L.kv2->d;
-  MGS_TRY(k_dot_dev(ctx, n, d1, L.kv1->d, sc + 0));
-  MGS_TRY(k_dot_dev(ctx, n, d1, rhs, sc + 1));
+  // the same products with c as left factor — ρ1 = c1·Ac1, α1 = c1·rhs, γ = c2·Ac1; then, with the second direction orthogonalised
+  // explicitly (c2' = c2 − (γ/ρ1)c1, v2' = v2 − (γ/ρ1)v1), ρ2 = d2'·v2' and α2 = d2'·r' (kernels_aux.hip: kc_orth_dots_kernel).
+  const bool energy = ctx->opt_kcycle_energy != 0;
+  const double *d1 = energy ? L.kc1->d : L.kv1->d, *d2 = energy ? L.kc2->d : L.kv2->d;
+  const double *two[2] = {L.kv1->d, rhs};
+  MGS_TRY(k_mdot(ctx, n, 2, d1, two, sc + 0, nullptr));                      // ρ1, α1: d1 read once
   MGS_TRY(kc_allreduce(h, sc, 2));
   MGS_TRY(k_kc_update_r(ctx, n, sc, rhs, L.kv1->d, L.kr->d));
   MGS_TRY(cycle_level(h, l, L.kr->d, L.kc2->d, true));
   MGS_TRY(sharded_op(h, l, L.A, MGS_OP_SPMV, L.kc2->d, nullptr, nullptr, 0.0, L.kv2->d));
-  MGS_TRY(k_dot_dev(ctx, n, d2, L.kv1->d, sc + 2));
-  MGS_TRY(k_dot_dev(ctx, n, d2, L.kv2->d, sc + 3));
-  MGS_TRY(k_dot_dev(ctx, n, d2, L.kr->d, sc + 4));
-  MGS_TRY(kc_allreduce(h, sc + 2, 3));
+  MGS_TRY(k_dot_dev(ctx, n, d2, L.kv1->d, sc + 2));                          // γ
+  MGS_TRY(kc_allreduce(h, sc + 2, 1));
+  MGS_TRY(k_kc_orth_dots(ctx, n, energy, sc, L.kc1->d, L.kc2->d, L.kv1->d, L.kv2->d, L.kr->d));   // ρ2, α2
+  MGS_TRY(kc_allreduce(h, sc + 3, 2));
   return k_kc_combine(ctx, n, sc, L.kc1->d, L.kc2->d, x);
 }
 
@@ -1433,10 +1446,17 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, in
   return mgs_sync(ctx);
 }
 
-// Flexible GCR(m): x += Σ α_k c_k with c_k = B_k r (variable preconditioner), v_k = A c_k orthogonalised
-// (modified Gram-Schmidt) against the previous v_j of the restart window.  The recursively updated residual r ← r − α v drifts
-// from b − A·x (the directions are orthogonalised in finite precision, and a K-cycle is a different operator at every call), so
-// the TRUE residual b − A·x replaces it at every restart and decides every return with status 0: the method never reports a
+// Flexible GCR(m): c_k = B_k r (variable preconditioner), v_k = A c_k orthogonalised against the v_j of the restart window, r ← r − α_k v_k.
+// Device passes per iteration beside the preconditioner and the SpMV (round 3 ran 8 vector passes and 3 host round trips PER EARLIER
+// DIRECTION — 39 % of a 512³ solve outside the preconditioner):
+//   * one multi-dot pass: h_j = v_j·v_k for every j < k, v_k read once (classical Gram-Schmidt; the window is ≤ 64 and restarted);
+//   * one update pass:    v_k ← v_k − Σ (h_j/ρ_j) v_j with ρ_k = v_k·v_k and t = v_k·r from the same pass;
+//   * one residual pass:  r ← r − (t/ρ_k) v_k with ‖r‖²;
+// and the directions c_k are NOT orthogonalised at all: with U_jk = h_j/ρ_j (strictly upper triangular) the orthogonalised directions are
+// Ĉ = C (I + U)⁻¹, so x − x₀ = Ĉ α = C y with (I + U) y = α — a back substitution on k ≤ 64 numbers on the host and ONE pass
+// x ← x + Σ y_j c_j when the window closes (restart, convergence, or the iteration limit).
+// The recursively updated residual drifts from b − A·x (finite-precision orthogonality, and a K-cycle is a different operator at every
+// call), so the TRUE residual b − A·x replaces it at every restart and decides every return with status 0: the method never reports a
 // tolerance it has not reached.  (A sliding window instead of the restart was measured on the CPU restatement,
 // tools/kcycle_diag_cpu.py, 64³: K-cycle on all levels 25 iterations restarted, 28–40 with a window of 10 — the restart stays.)
 int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int restart, int *max_iter, double *tol, int *status) {
@@ -1445,14 +1465,15 @@ int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int re
   MGS_CHECK(ctx, A->rows == A->cols && x->n >= A->rows && b->n >= A->rows, MGS_ERR_INVALID, "mgs_fgcr: square unsharded operator required");
   MGS_TRY(mgs_csr_optimize(const_cast<mgs_csr *>(A)));
   const int n = A->rows;
+  constexpr int CH = 16;                             // vectors per multi-vector pass (kernels_aux.hip: MDOT_MAX)
   struct Guard { mgs_ctx *c; std::vector<mgs_vec *> vs; ~Guard() { hipStreamSynchronize(c->stream); for (auto q : vs) ws_put(c, q); } } guard{ctx, {}};
   auto mk = [&](mgs_vec **q) -> int { int rc = ws_get(ctx, n, n, q); if (rc == MGS_OK) guard.vs.push_back(*q); return rc; };
   mgs_vec *r = nullptr; MGS_TRY(mk(&r));
   std::vector<mgs_vec *> C((size_t)restart, nullptr), V((size_t)restart, nullptr);
-  std::vector<double> rho((size_t)restart, 0.0);
+  std::vector<double> rho((size_t)restart, 0.0), alpha((size_t)restart, 0.0), U((size_t)restart * restart, 0.0), hj((size_t)restart, 0.0), y((size_t)restart, 0.0);
   mgs_vec xv; xv.ctx = ctx; xv.n = n; xv.d = x->d; xv.owns = false;
   mgs_vec bv; bv.ctx = ctx; bv.n = n; bv.d = b->d; bv.owns = false;
-  double normb = 0, nr = 0, t = 0;
+  double normb = 0, nr = 0;
   MGS_TRY(mgs_nrm2(&bv, &normb));
   if (normb == 0.0) normb = 1;
   auto true_residual = [&](double *resid_out) -> int {      // r = b − A·x, ‖r‖/‖b‖
@@ -1461,40 +1482,71 @@ int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int re
     *resid_out = nr / normb;
     return MGS_OK;
   };
+  // x ← x + Σ_{j<m} y_j c_j, (I + U) y = α over the m directions of the open window
+  auto close_window = [&](int m) -> int {
+    if (m <= 0) return MGS_OK;
+    for (int k = m - 1; k >= 0; --k) { double s = alpha[k]; for (int q = k + 1; q < m; ++q) s -= U[(size_t)k * restart + q] * y[q]; y[k] = s; }
+    for (int c0 = 0; c0 < m; c0 += CH) {
+      const int K = std::min(CH, m - c0);
+      const double *w[CH]; double cf[CH];
+      for (int q = 0; q < K; ++q) { w[q] = C[c0 + q]->d; cf[q] = -y[c0 + q]; }
+      MGS_TRY(k_maxpy_dot2(ctx, n, K, xv.d, w, cf, xv.d, nullptr, nullptr, nullptr));
+    }
+    return MGS_OK;
+  };
   double resid = 0.0;
   MGS_TRY(true_residual(&resid));
   if (resid <= *tol) { *tol = resid; *max_iter = 0; *status = 0; return MGS_OK; }
   int it = 0;
   while (it < *max_iter) {
-    for (int k = 0; k < restart && it < *max_iter; ++k) {
+    int m = 0;                                       // directions in the open window
+    bool restart_now = false;
+    for (int k = 0; k < restart && it < *max_iter && !restart_now; ++k) {
       if (!C[k]) { MGS_TRY(mk(&C[k])); MGS_TRY(mk(&V[k])); }
       if (h) MGS_TRY(mgs_vcycle(h, r, C[k], 1)); else MGS_TRY(mgs_vec_copy(r, C[k]));
       MGS_TRY(mgs_spmv(A, C[k], V[k]));
-      for (int j = 0; j < k; ++j) {
-        MGS_TRY(mgs_dot(V[j], V[k], &t));
-        const double beta = rho[j] != 0.0 ? t / rho[j] : 0.0;
-        MGS_TRY(mgs_axpby(-beta, V[j], 1.0, V[k]));
-        MGS_TRY(mgs_axpby(-beta, C[j], 1.0, C[k]));
+      double d2[2];
+      if (k == 0) {
+        MGS_TRY(k_dot2(ctx, n, V[0]->d, V[0]->d, V[0]->d, r->d, d2));
+      } else {
+        for (int c0 = 0; c0 < k; c0 += CH) {           // every h_j against the SAME (not yet updated) v_k
+          const int K = std::min(CH, k - c0);
+          const double *w[CH];
+          for (int q = 0; q < K; ++q) w[q] = V[c0 + q]->d;
+          MGS_TRY(k_mdot(ctx, n, K, V[k]->d, w, nullptr, &hj[(size_t)c0]));
+        }
+        for (int j = 0; j < k; ++j) U[(size_t)j * restart + k] = rho[j] != 0.0 ? hj[j] / rho[j] : 0.0;
+        for (int c0 = 0; c0 < k; c0 += CH) {
+          const int K = std::min(CH, k - c0);
+          const bool last = c0 + CH >= k;
+          const double *w[CH]; double cf[CH];
+          for (int q = 0; q < K; ++q) { w[q] = V[c0 + q]->d; cf[q] = U[(size_t)(c0 + q) * restart + k]; }
+          MGS_TRY(k_maxpy_dot2(ctx, n, K, V[k]->d, w, cf, V[k]->d, last ? r->d : nullptr, nullptr, last ? d2 : nullptr));
+        }
       }
-      MGS_TRY(mgs_dot(V[k], V[k], &rho[k]));
-      ++it;
-      if (rho[k] == 0.0) { MGS_TRY(true_residual(&resid)); *status = resid < *tol ? 0 : 2; *tol = resid; *max_iter = it; return mgs_sync(ctx); }
-      MGS_TRY(mgs_dot(V[k], r, &t));
-      const double alpha = t / rho[k];
-      MGS_TRY(mgs_axpby(alpha, C[k], 1.0, &xv));
-      MGS_TRY(mgs_axpby(-alpha, V[k], 1.0, r));
-      MGS_TRY(mgs_nrm2(r, &nr));
-      resid = nr / normb;
+      rho[k] = d2[0];
+      ++it; m = k + 1;
+      if (rho[k] == 0.0) {                             // A·c_k lies in the span of the window: nothing more to gain from it
+        alpha[k] = 0.0;
+        MGS_TRY(close_window(m));
+        MGS_TRY(true_residual(&resid)); *status = resid < *tol ? 0 : 2; *tol = resid; *max_iter = it; return mgs_sync(ctx);
+      }
+      alpha[k] = d2[1] / rho[k];
+      MGS_TRY(k_update_dot2(ctx, n, 1.0, r->d, -alpha[k], V[k]->d, r->d, nullptr, d2));   // r ← r − α v with ‖r‖²
+      resid = std::sqrt(d2[0]) / normb;
       if (resid < *tol) {                         // the recursion says converged: the true residual decides
+        MGS_TRY(close_window(m)); m = 0;
         MGS_TRY(true_residual(&resid));
         if (resid < *tol) { *tol = resid; *max_iter = it; *status = 0; return mgs_sync(ctx); }
-        break;                                    // not yet: restart from the true residual (r holds it)
+        restart_now = true;                       // not yet: restart from the true residual (r holds it)
       }
     }
-    if (it < *max_iter) MGS_TRY(true_residual(&resid));      // restart: r ← b − A·x
-    if (resid < *tol) { *tol = resid; *max_iter = it; *status = 0; return mgs_sync(ctx); }
+    if (m) {                                      // window full (or out of iterations): x catches up, r ← b − A·x
+      MGS_TRY(close_window(m));
+      MGS_TRY(true_residual(&resid));
+      if (resid < *tol) { *tol = resid; *max_iter = it; *status = 0; return mgs_sync(ctx); }
+    }
   }
-  MGS_TRY(true_residual(&resid));
   *status = resid < *tol ? 0 : 1; *tol = resid; *max_iter = it;
   return mgs_sync(ctx);
 }

@@ -12,6 +12,7 @@
 
 #include "../../include/mgs.h"
 
+constexpr int MGS_RED_VALS = 32;   // results one reduction can hand to the host (mgs_ctx::red_host)
 struct mgs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -21,7 +22,7 @@ struct mgs_ctx {
   double *dot_part = nullptr; int64_t dot_part_cap = 0;   // per-row-block partials of the dots fused into the SpMV epilogue
   double *red_dev = nullptr;
   std::vector<struct mgs_vec *> ws_free;   // work vectors of the Krylov solvers, kept between solves (mgs_ctx_trim releases them)
-  double *red_host = nullptr;       // 16 doubles, mapped + coherent: [0..8) values, [8] the ticket of the posted-result path
+  double *red_host = nullptr;       // 2·MGS_RED_VALS doubles, mapped + coherent: [0..MGS_RED_VALS) values, [MGS_RED_VALS] the ticket of the posted-result path
   double *red_host_dev = nullptr;   // the same buffer as the device sees it (NULL: not mappable, copy + synchronize)
   unsigned long long red_ticket = 0;
   int red_cap = 0;
@@ -144,6 +145,15 @@ int mgs_comm_exchange_ops(mgs_comm *c, const mgs_xfer_op *ops, int nops);       
 int mgs_comm_allgather(mgs_comm *c, const double *send, double *recv, size_t count);
 int mgs_comm_allreduce_sum(mgs_comm *c, double *buf, size_t count);
 bool mgs_comm_capturable(const mgs_comm *c);   // false for the file-based stand-in of the tests (host-synchronous calls)
+// peer-to-peer transport behind the same three operations (comm_p2p.hip): IPC-mapped windows, one kernel per exchange
+struct mgs_p2p;
+int mgs_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void *handle_out, mgs_p2p **out);
+int mgs_p2p_connect(mgs_p2p *c, const void *handles);
+void mgs_p2p_destroy(mgs_p2p *c);
+int mgs_p2p_info(const mgs_p2p *c, long long out[6]);
+int mgs_p2p_exchange_ops(mgs_p2p *c, hipStream_t s, const mgs_xfer_op *ops, int nops);
+int mgs_p2p_allgather(mgs_p2p *c, hipStream_t s, const double *send, double *recv, size_t count);
+int mgs_p2p_allreduce_sum(mgs_p2p *c, hipStream_t s, double *buf, size_t count);
 // halo plan of one sharded level for the native exchange
 struct mgs_native_plan {
   mgs_comm *comm = nullptr;
@@ -340,7 +350,10 @@ int k_dot2_finish(mgs_ctx *ctx, int nb, const double *part /*[2][nb]*/, double *
 // y = A·x with (y·w1, y·y) from the same pass where the pattern-coded kernel serves A (else SpMV + k_dot2): BiCGSTAB's
 // v = A·p̂ with r̃·v (bicg.cpp:107-108) and t = A·ŝ with (t·s, t·t) (bicg.cpp:117-118)
 int mgs_spmv_dots(const mgs_csr *A, const double *x, double *y, const double *w1, double *out_host2);
+int k_mdot(mgs_ctx *ctx, int64_t n, int K, const double *a, const double *const *b, double *out_dev, double *out_host);   // a·b_k, k < K ≤ 16, one pass
+int k_maxpy_dot2(mgs_ctx *ctx, int64_t n, int K, const double *x, const double *const *w, const double *coef, double *z, const double *u, const double *u2, double *out_host2);
 int k_kc_update_r(mgs_ctx *ctx, int n, const double *scal, const double *r, const double *v1, double *rp);
+int k_kc_orth_dots(mgs_ctx *ctx, int n, bool energy, double *scal, const double *c1, const double *c2, const double *v1, const double *v2, const double *rp);
 int k_kc_combine(mgs_ctx *ctx, int n, const double *scal, const double *c1, const double *c2, double *x);
 int k_dense_inverse(mgs_ctx *ctx, const mgs_csr *A, double **inv_out);
 int k_poisson3d(mgs_ctx *ctx, int N, int plane_lo, int plane_hi, int local_cols, mgs_csr **out);

@@ -431,20 +431,34 @@ class ShardedHierarchy:
             self.h.set_halo_exchange(self._exchange)
         if fused:
             self.h.set_halo_exchange_fused(self._exchange_fused)
+        # native transports, in the order tried (MGS_NATIVE_TRANSPORT, default "p2p,rccl"): "p2p" = the library's own peer-to-peer
+        # exchange kernels over IPC-mapped device windows (csrc/comm_p2p.hip; any torch backend serves the setup handshakes), "rccl" =
+        # ncclSend/ncclRecv groups (needs the nccl backend, or MGS_NATIVE_RCCL=force with a stand-in library: tests)
+        env = os.environ.get("MGS_NATIVE_RCCL", "1")
+        order = [t_ for t_ in os.environ.get("MGS_NATIVE_TRANSPORT", "p2p,rccl").split(",") if t_ in ("p2p", "rccl")]
+        if env == "force":
+            order = [t_ for t_ in order if t_ == "rccl"] if "MGS_NATIVE_TRANSPORT" not in os.environ else order
+        elif not comm.nccl:
+            order = [t_ for t_ in order if t_ == "p2p"]
         if native is None:
-            env = os.environ.get("MGS_NATIVE_RCCL", "1")      # "force": also without the nccl backend (tests: MGS_LIBRCCL → stand-in)
-            native = env == "force" or (comm.nccl and env != "0")
-        self.native = bool(native) and self._enable_native(log)
+            native = env != "0" and bool(order) and comm.device.type == "cuda"
+        self.native, self.native_transport = False, None
+        if native:
+            for tr in order:
+                if self._enable_native(log, transport=tr):
+                    self.native, self.native_transport = True, tr
+                    break
         # capture the native cycle (RCCL exchanges included) in a hipGraph: MGS_NATIVE_GRAPH=0 keeps eager launches
         ctx.set_option("native_graph", 0 if os.environ.get("MGS_NATIVE_GRAPH", "1") == "0" else 1)
         return self
 
     # ---- native RCCL transport: the C++ cycle packs, exchanges (ncclSend/ncclRecv) and gathers the tail by itself
-    def _enable_native(self, log=None):
-        """Creates the library's own RCCL communicator (unique id shipped through torch.distributed), hands every
-        sharded level's plan and the tail to the C++ cycle, and cross-checks one native halo exchange per level
-        against the torch.distributed path bit for bit on every rank.  Any failure on any rank → all ranks stay
-        on the callback path (returns False)."""
+    def _enable_native(self, log=None, transport="rccl"):
+        """Creates the library's own communicator — transport "rccl": an RCCL communicator (unique id shipped through
+        torch.distributed); "p2p": IPC-mapped device windows, one exchange kernel per halo exchange — hands every
+        sharded level's plan and the tail to the C++ cycle, and cross-checks native halo exchanges on every level
+        against the torch.distributed path bit for bit on every rank.  Any failure on any rank → all ranks drop
+        this transport (returns False)."""
         t, comm, ctx = self.torch, self.comm, self.ctx
 
         def agree(flag):
@@ -453,34 +467,60 @@ class ShardedHierarchy:
 
         ok = True
         self._seg_args = []
-        # the RCCL copy this process already uses (torch's); MGS_LIBRCCL overrides the path
-        path = os.environ.get("MGS_LIBRCCL", os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")).encode()
-        idbuf = C.create_string_buffer(128)
-        try:      # local preflight on every rank: the library resolves RCCL and can mint an id
-            check(lib().mgs_comm_unique_id(ctx.h, path, idbuf), ctx.h)
-        except Exception as e:  # noqa: BLE001
-            ok = False
-            if log:
-                log(f"native RCCL transport unavailable on this rank: {e!r}")
-        if not agree(ok):
-            if log:
-                log("exchange transport: torch.distributed callbacks")
-            return False
-        idbuf = C.create_string_buffer(comm.broadcast_object(idbuf.raw, src=0), 128)            # rank 0's id
+        tname = "native RCCL transport" if transport == "rccl" else "peer-to-peer transport"
+        if transport == "rccl":
+            # the RCCL copy this process already uses (torch's); MGS_LIBRCCL overrides the path
+            path = os.environ.get("MGS_LIBRCCL", os.path.join(os.path.dirname(t.__file__), "lib", "librccl.so")).encode()
+            idbuf = C.create_string_buffer(128)
+            try:      # local preflight on every rank: the library resolves RCCL and can mint an id
+                check(lib().mgs_comm_unique_id(ctx.h, path, idbuf), ctx.h)
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                if log:
+                    log(f"native RCCL transport unavailable on this rank: {e!r}")
+            if not agree(ok):
+                if log:
+                    log("exchange transport: torch.distributed callbacks")
+                return False
+            idbuf = C.create_string_buffer(comm.broadcast_object(idbuf.raw, src=0), 128)            # rank 0's id
         def fail(stage, e=None):
             if log:
-                log(f"native RCCL transport: {stage} failed" + (f" ({e!r})" if e is not None else "") + " -> torch.distributed callbacks")
+                log(f"{tname}: {stage} failed" + (f" ({e!r})" if e is not None else "") + " -> next transport")
             self._drop_native()
             return False
 
         c = C.c_void_p()
-        try:      # collective: every rank is here
-            check(lib().mgs_comm_create(ctx.h, path, idbuf, comm.world, comm.rank, C.byref(c)), ctx.h)
-            self._ncomm = c
-        except Exception as e:  # noqa: BLE001
-            ok = False; err = e
-        if not agree(ok):
-            return fail("communicator creation", locals().get("err"))
+        if transport == "rccl":
+            try:      # collective: every rank is here
+                check(lib().mgs_comm_create(ctx.h, path, idbuf, comm.world, comm.rank, C.byref(c)), ctx.h)
+                self._ncomm = c
+            except Exception as e:  # noqa: BLE001
+                ok = False; err = e
+            if not agree(ok):
+                return fail("communicator creation", locals().get("err"))
+        else:
+            # window slot = the most doubles one peer ever stores here in one exchange (halo of any level, or its slice of the tail's
+            # right-hand side); the same on every rank (windows are symmetric)
+            need = np.array([float(max([64, int(self.tail_nlocs.max())] + [max(p.recv_counts + p.send_counts + [0]) for p in self.plans]))])
+            comm.allreduce_host(need, op="max")
+            from ._lib import P2P_HANDLE_BYTES
+            hbuf = C.create_string_buffer(P2P_HANDLE_BYTES)
+            try:
+                if comm.world > 8:
+                    raise RuntimeError("peer-to-peer transport: at most 8 ranks")
+                check(lib().mgs_comm_p2p_create(ctx.h, comm.world, comm.rank, int(need[0]), hbuf, C.byref(c)), ctx.h)
+                self._ncomm = c
+            except Exception as e:  # noqa: BLE001
+                ok = False; err = e
+            if not agree(ok):
+                return fail("window creation", locals().get("err"))
+            handles = b"".join(comm.all_gather_object(hbuf.raw))          # rank order
+            try:
+                check(lib().mgs_comm_p2p_connect(c, C.create_string_buffer(handles, len(handles))), ctx.h)
+            except Exception as e:  # noqa: BLE001
+                ok = False; err = e
+            if not agree(ok):
+                return fail("mapping the peers' windows", locals().get("err"))
         try:      # local: plans and tail into the C++ cycle
             ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.c_void_p)  # noqa: E731
             for l, plan in enumerate(self.plans):
@@ -502,6 +542,8 @@ class ShardedHierarchy:
         # and installs what it will receive — collective, all levels or none (a rank that cannot keeps every rank on packed sends).
         segs, ok = [], True
         try:
+            if os.environ.get("MGS_NATIVE_SEGMENTS", "1") == "0":
+                raise RuntimeError("MGS_NATIVE_SEGMENTS=0")
             for l, plan in enumerate(self.plans):
                 nseg = (C.c_int * comm.world)(); cap = sum(plan.send_counts) + comm.world + 1
                 lens = (C.c_int * cap)()
@@ -541,24 +583,26 @@ class ShardedHierarchy:
                 log(f"native exchanges keep the pack kernel ({locals().get('err')!r})")
         elif log:
             log(f"native exchanges keep the pack kernel ({locals().get('err')!r})")
-        # collective: one native halo exchange per level against the torch.distributed exchange, bit for bit
+        # collective: native halo exchanges per level against the torch.distributed exchange, bit for bit (p2p: three rounds with fresh
+        # data, so both window slots are written, read and written again)
         for l, plan in enumerate(self.plans):
-            try:
-                n_ext = plan.n_loc + plan.n_halo
-                xa = ctx.vec(n_ext).rand(seed=1234 + l, offset=comm.rank * 7919); xb = ctx.vec(n_ext)
-                check(lib().mgs_vec_copy(xa.h, xb.h), ctx.h)
-                ctx.sync()
-                with comm.host_ops():                      # the torch collective's events stay off the context's stream
-                    self._exchange(l, xa.ptr, sync_pack=True); t.cuda.current_stream().synchronize()
-                check(lib().mgs_hier_native_halo(self.h.h, l, C.c_void_p(xb.ptr)), ctx.h)
-                ctx.sync(); t.cuda.synchronize()
-                same = bool(np.array_equal(xa.numpy(), xb.numpy()))
-            except Exception as e:  # noqa: BLE001
-                same = False; err = e
-            if not agree(same):
-                return fail(f"cross-check of the level-{l} exchange", locals().get("err"))
+            for rnd in range(3 if transport == "p2p" else 1):
+                try:
+                    n_ext = plan.n_loc + plan.n_halo
+                    xa = ctx.vec(n_ext).rand(seed=1234 + l + 100 * rnd, offset=comm.rank * 7919); xb = ctx.vec(n_ext)
+                    check(lib().mgs_vec_copy(xa.h, xb.h), ctx.h)
+                    ctx.sync()
+                    with comm.host_ops():                      # the torch collective's events stay off the context's stream
+                        self._exchange(l, xa.ptr, sync_pack=True); t.cuda.current_stream().synchronize()
+                    check(lib().mgs_hier_native_halo(self.h.h, l, C.c_void_p(xb.ptr)), ctx.h)
+                    ctx.sync(); t.cuda.synchronize()
+                    same = bool(np.array_equal(xa.numpy(), xb.numpy()))
+                except Exception as e:  # noqa: BLE001
+                    same = False; err = e
+                if not agree(same):
+                    return fail(f"cross-check of the level-{l} exchange", locals().get("err"))
         if log:
-            log("exchange transport: native RCCL inside the C++ cycle (verified against torch.distributed)")
+            log(f"exchange transport: {tname} inside the C++ cycle (verified against torch.distributed)")
         # torch's collective watchdog retires finished work every 100 ms: let it finish before the first cycle is captured
         t.cuda.synchronize(); import time; time.sleep(0.35)
         return True
@@ -746,6 +790,19 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
     elapsed, ms_k, ms_x = float(el[0]), float(el[1]), float(el[2])
     beat("solve check")
     st, it, tol = sh.bicgstab(ctx.vec(n_ext), b, 300, 1e-10)
+    # peer-to-peer transport: its device-side waits are bounded (MGS_P2P_TIMEOUT_S); a wait that timed out left an error word — this
+    # generation's numbers are void, the worker exits non-zero and the launcher moves on
+    p2p_info = None
+    if getattr(sh, "native_transport", None) == "p2p" and getattr(sh, "_ncomm", None) is not None:
+        inf = (C.c_longlong * 6)()
+        check(lib().mgs_comm_p2p_info(sh._ncomm, inf), ctx.h)
+        p2p_info = {"window_memory": {1: "uncached", 2: "fine-grained", 3: "coarse-grained"}.get(int(inf[0]), "?"), "window_bytes": int(inf[1]),
+                    "slot_doubles": int(inf[2]), "exchange_kernels_launched": int(inf[3]), "error_word": int(inf[4])}
+        bad = np.array([float(inf[4] != 0)]); comm.allreduce_host(bad, op="max")
+        if bad[0] > 0:
+            raise RuntimeError(f"peer-to-peer transport: a wait timed out on some rank (this rank's error word {int(inf[4])})")
+    if st != 0:
+        raise RuntimeError(f"sharded BiCGSTAB + V-cycle did not converge on the {getattr(sh, 'native_transport', None) or 'callback'} transport: status {st}, {it} iterations, tol {tol:.2e}")
     out = None
     if rank == 0:
         n, nnz = N ** 3, 7 * N ** 3 - 6 * N * N
@@ -768,16 +825,18 @@ def bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json=None
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"poisson3d_{N}^3_7pt (BASELINE.json configs[4]) row-sharded by plane ranges; V({args.nu1},{args.nu2}) "
                                       f"damped-Jacobi cycle, omega={args.omega}, device-built hierarchy ktg={args.ktg} npass={args.npass} tou={args.tou}",
-                          "grid": N, "rows": n, "nnz": nnz, "parallelism": f"row-shard x{world} (" + ("native RCCL send/recv inside the C++ cycle" if sh.native else "torch.distributed all_to_all callbacks") + ", replicated coarse tail)",
+                          "grid": N, "rows": n, "nnz": nnz, "parallelism": f"row-shard x{world} (" + ({"p2p": "peer-to-peer exchange kernels over IPC-mapped device windows inside the C++ cycle", "rccl": "native RCCL send/recv inside the C++ cycle"}.get(sh.native_transport, "?") if sh.native else "torch.distributed all_to_all callbacks") + ", replicated coarse tail)",
                           "sharded_levels": len(sh.plans), "total_levels": sh.nlev, "setup_seconds": t_setup},
-               "transport": {"backend": dist.get_backend(), "world": world, "rank": rank, "native_rccl": bool(sh.native),
+               "transport": {"backend": dist.get_backend(), "world": world, "rank": rank, "native": sh.native_transport if sh.native else None,
+                             "native_rccl": bool(sh.native and sh.native_transport == "rccl"), "p2p": p2p_info,
                              "mgs_comm_size": [cw.value, cr.value] if ncomm is not None else None,
                              "cycle_graph": graph_info, "generation": os.environ.get("MGS_BENCH_GEN_NAME"),
                              "exchanges_per_cycle_callbacks": None if sh.native else ex_per_cycle},
                # a run that completed on a later generation of the launcher (slower transport) says so at top level
                "degraded": bool(launch.abandoned_generations()), "abandoned_generations": launch.abandoned_generations(),
-               "multi_gpu_note": "the native RCCL transport with the cycle captured in one hipGraph has run on real links only where a scaling run of the "
-                                 "driver exists (see README / DESIGN.md §7); transport.generation names what this line was measured on",
+               "multi_gpu_note": "N > 1 has NOT run on real links before this line unless a scaling run of the driver exists (DESIGN.md §7): the native transports "
+                                 "(peer-to-peer windows, RCCL groups) were verified with several ranks sharing ONE GPU; this run cross-checked every level's exchange "
+                                 "against torch.distributed bit for bit at setup and its solve converged; transport.generation names what this line was measured on",
                # whole-job rates of the sharded fine-level SpMV including its halo exchange: bytes that cross HBM (PMC traffic of the
                # full-grid launch) resp. the §8d-d3 CSR byte count, over the slowest rank's time
                "spmv_hbm_gbps": (tr[0] if tr else (streamed or loc_bytes) * n / n_loc) / (ms_x * 1e-3) / 1e9,

@@ -21,6 +21,7 @@ reasons the earlier generations were abandoned for).
 Nothing here touches the GPU or imports torch.
 """
 import os
+import shutil
 import signal
 import socket
 import subprocess
@@ -32,23 +33,44 @@ import time
 EXIT_RETRY = 77
 # (name, environment overrides) — most capable first
 GENERATIONS = (
-    ("native-rccl+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1"}),
-    ("native-rccl", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "0"}),
+    # the library's own peer-to-peer exchange kernels over IPC-mapped device windows (csrc/comm_p2p.hip), cycle captured in a hipGraph;
+    # a wait that never ends times out on the device (MGS_P2P_TIMEOUT_S) and the worker exits non-zero: no watchdog period is spent
+    ("native-p2p+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "p2p"}),
+    # RCCL send/recv groups inside the captured cycle, in their most conservative form: one packed message per peer (the pack-free
+    # range sends post several ncclSend/ncclRecv per peer in one group — never run on real RCCL)
+    ("native-rccl+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "rccl", "MGS_NATIVE_SEGMENTS": "0"}),
+    ("native-rccl", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "0", "MGS_NATIVE_TRANSPORT": "rccl", "MGS_NATIVE_SEGMENTS": "0"}),
     ("torch.distributed-callbacks", {"MGS_NATIVE_RCCL": "0", "MGS_NATIVE_GRAPH": "0"}),
     ("gloo-host-staged", {"MGS_NATIVE_RCCL": "0", "MGS_NATIVE_GRAPH": "0", "MGS_DIST_BACKEND": "gloo"}),
 )
+# Time budget (the driver gives one bench run 600 s): a generation that hangs costs one watchdog period — 100 s by default
+# (MGS_BENCH_WATCHDOG_S; the longest silent phase of a healthy run is the first `import torch` on a fresh box, 1-2 min, which happens
+# BEFORE the watchdog starts) — and generations are skipped once MGS_BENCH_BUDGET_S (default 420 s) of the run are gone, so that the last
+# resort (host-staged gloo) still has time to finish: two failed generations + one good one + the bounded CPU baseline stay under 600 s.
+BUDGET_S = float(os.environ.get("MGS_BENCH_BUDGET_S", "420"))
 
 
 def first_generation(env=None):
     """the generation a run starts in: an explicit MGS_NATIVE_RCCL=0 / MGS_DIST_BACKEND=gloo skips what it rules out"""
     env = os.environ if env is None else env
     if env.get("MGS_DIST_BACKEND") == "gloo":
-        return 3 if env.get("MGS_NATIVE_RCCL") != "force" else 1
+        return 4 if env.get("MGS_NATIVE_RCCL") != "force" else 2
     if env.get("MGS_NATIVE_RCCL") == "0":
-        return 2
+        return 3
     if env.get("MGS_NATIVE_GRAPH") == "0":
+        return 2
+    if env.get("MGS_NATIVE_TRANSPORT") == "rccl":
         return 1
     return 0
+
+
+def next_generation(gen, t_start, log=lambda *a: None):
+    """the generation to try after `gen` failed: the next one, or — once the run's time budget is spent — the last resort"""
+    nxt = gen + 1
+    if nxt < len(GENERATIONS) - 1 and time.monotonic() - t_start > BUDGET_S:
+        log(f"{time.monotonic() - t_start:.0f}s of the run are gone (budget {BUDGET_S:.0f}s): skipping to the last generation")
+        return len(GENERATIONS) - 1
+    return nxt
 
 
 def free_port():
@@ -61,7 +83,7 @@ class Watchdog:
     """worker side: `beat(phase)` at every milestone; no beat for `limit` seconds → diagnostic + os._exit(77)"""
 
     def __init__(self, limit=None, out=sys.stderr):
-        self.limit = float(os.environ.get("MGS_BENCH_WATCHDOG_S", "150")) if limit is None else float(limit)
+        self.limit = float(os.environ.get("MGS_BENCH_WATCHDOG_S", "100")) if limit is None else float(limit)
         self.phase, self.t, self.out, self._stop = "start", time.monotonic(), out, False
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
@@ -156,6 +178,9 @@ def abandoned_generations():
 def _worker_env(base, gen, rank, local_rank, world, addr, port, rundir):
     env = dict(base)
     env.update(GENERATIONS[gen][1])
+    for k in ("MGS_NATIVE_SEGMENTS",):            # an explicit choice of the caller survives the generation's default
+        if k in base:
+            env[k] = base[k]
     if base.get("MGS_NATIVE_RCCL") == "force" and GENERATIONS[gen][1].get("MGS_NATIVE_RCCL") == "1":
         env["MGS_NATIVE_RCCL"] = "force"          # tests: stand-in RCCL without the nccl backend
     if base.get("MGS_DIST_BACKEND") and "MGS_DIST_BACKEND" not in GENERATIONS[gen][1]:
@@ -164,6 +189,26 @@ def _worker_env(base, gen, rank, local_rank, world, addr, port, rundir):
                RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR=addr, MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return env
+
+
+def _proc_start(pid):
+    """start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat); 0 if unreadable"""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
+def _proc_start_monotonic(pid):
+    """time.monotonic() value at which process `pid` started (CLOCK_MONOTONIC and /proc start times both count from boot)"""
+    st = _proc_start(pid)
+    if not st:
+        return time.monotonic()
+    try:
+        return st / os.sysconf("SC_CLK_TCK")
+    except (ValueError, OSError):
+        return time.monotonic()
 
 
 def _kill(p):
@@ -184,10 +229,15 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
     Returns the exit code for the caller to exit with (0 = some generation completed on every rank)."""
     import json
     rundir = tempfile.mkdtemp(prefix="mgs_bench_")
-    limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "1500")) if total_timeout is None else total_timeout
+    limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "400")) if total_timeout is None else total_timeout
     rc_final = 1
     abandoned = []
-    for gen in range(first_generation(), len(GENERATIONS)):
+    t_start = time.monotonic()
+    gen = first_generation() - 1
+    while True:
+        gen = next_generation(gen, t_start, log) if gen >= first_generation() else first_generation()
+        if gen >= len(GENERATIONS):
+            break
         port = free_port()
         base = dict(os.environ, MGS_BENCH_ABANDONED=json.dumps(abandoned))
         procs = [subprocess.Popen([sys.executable] + argv, env=_worker_env(base, gen, r, r, world, "127.0.0.1", port, rundir))
@@ -199,6 +249,7 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
             done = [c == 0 or (c is not None and os.path.exists(_marker(rundir, gen, r))) for r, c in enumerate(codes)]
             if all(done):
                 _relay_unprinted(rundir, gen)            # rank 0 finished its measurement but died before printing it
+                shutil.rmtree(rundir, ignore_errors=True)
                 return 0
             failed = [r for r, c in enumerate(codes) if c is not None and not done[r]]
             if failed:
@@ -213,6 +264,7 @@ def spawn_ranks(argv, world, log=lambda *a: None, total_timeout=None):
         rc_final = next((c for c in (p.returncode for p in procs) if c not in (0, None)), 1)
         abandoned.append({"generation": GENERATIONS[gen][0], "reason": bad})
         log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned: {bad}")
+    shutil.rmtree(rundir, ignore_errors=True)
     return rc_final
 
 
@@ -226,20 +278,33 @@ def supervise_rank(argv, log=lambda *a: None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     addr, port0 = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
-    # the launcher agent is the common parent of the rank slots: its pid makes the directory unique to this run
-    rundir = os.path.join(tempfile.gettempdir(), f"mgs_bench_{port0}_{os.getppid()}")
+    # the launcher agent is the common parent of the rank slots: its pid AND its start time (plus the launcher's run id) make the
+    # directory unique to this run — a recycled pid/port pair of an earlier run in the same container names another directory, so no
+    # stale fail.g* / result.g* / done.g* file can ever be seen (advisor, round 3)
+    rundir = os.path.join(tempfile.gettempdir(), f"mgs_bench_{port0}_{os.getppid()}_{_proc_start(os.getppid())}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
     os.makedirs(rundir, exist_ok=True)
-    for gen in range(len(GENERATIONS)):               # leftovers of an earlier run with the same pid and port (own files only:
-        for path in (_marker(rundir, gen, rank),):    # the shared fail/result files are keyed by generation and cleared by rank 0 below)
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
-    limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "1500"))
+    limit = float(os.environ.get("MGS_BENCH_GEN_TIMEOUT_S", "400"))
     rc = 1
     g0 = first_generation()
     abandoned = []
-    for gen in range(g0, len(GENERATIONS)):
+    t_start = _proc_start_monotonic(os.getppid())      # run time counts from the launcher's start
+
+    def leave(code):
+        """this slot's files go; the last slot out removes the directory (rank 0 also drops the shared files once the run succeeded)"""
+        for g in range(len(GENERATIONS)):
+            for path in [_marker(rundir, g, rank)] + ([_fail_file(rundir, g), _result_file(rundir, g)] if (rank == 0 and code == 0) else []):
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        try:
+            os.rmdir(rundir)
+        except OSError:
+            pass
+        return code
+
+    gen = g0
+    while gen < len(GENERATIONS):
         base = dict(os.environ, MGS_BENCH_ABANDONED=json.dumps(abandoned))
         env = _worker_env(base, gen, rank, local_rank, world, addr, port0 if gen == g0 else port0 + 1 + gen, rundir)
         if gen != g0:
@@ -252,17 +317,14 @@ def supervise_rank(argv, log=lambda *a: None):
                 if rc == 0 or os.path.exists(_marker(rundir, gen, rank)):
                     if rank == 0:
                         _relay_unprinted(rundir, gen)
-                    return 0
+                    return leave(0)
                 reason = f"rank {rank} worker exited with {rc}"
                 break
             if os.path.exists(_fail_file(rundir, gen)):          # another rank's worker failed: leave this generation with it
-                try:
-                    reason = open(_fail_file(rundir, gen)).read().strip() or "another rank failed"
-                except OSError:
-                    reason = "another rank failed"
+                reason = "another rank failed"
                 if os.path.exists(_marker(rundir, gen, rank)):   # this rank's part was complete already: nothing to redo here
                     _kill(p)
-                    return 0
+                    return leave(0)
                 _kill(p); rc = EXIT_RETRY
                 break
             if time.monotonic() - t0 > limit:
@@ -270,20 +332,32 @@ def supervise_rank(argv, log=lambda *a: None):
                 _kill(p); rc = EXIT_RETRY
                 break
             time.sleep(0.1)
-        if not os.path.exists(_fail_file(rundir, gen)):            # first to fail: tell the others (atomic create; losers keep the winner's reason)
+        # first to fail: tell the others why AND which generation comes next (atomic create; the losers keep the winner's record, so every
+        # slot moves to the SAME generation even when the time budget runs out just now)
+        nxt = next_generation(gen, t_start)
+        if not os.path.exists(_fail_file(rundir, gen)):
             try:
-                fd = os.open(_fail_file(rundir, gen), os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
-                os.write(fd, (reason or "failed").encode()); os.close(fd)
+                fd = os.open(_fail_file(rundir, gen) + f".{rank}", os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
+                os.write(fd, f"next={nxt}\n{reason or 'failed'}".encode()); os.close(fd)
+                os.link(_fail_file(rundir, gen) + f".{rank}", _fail_file(rundir, gen))     # appears complete or not at all
+            except OSError:
+                pass
+            try:
+                os.unlink(_fail_file(rundir, gen) + f".{rank}")
             except OSError:
                 pass
         try:
-            reason = open(_fail_file(rundir, gen)).read().strip() or reason
-        except OSError:
+            rec = open(_fail_file(rundir, gen)).read().strip().split("\n", 1)
+            if rec[0].startswith("next="):
+                nxt = int(rec[0][5:]); rec = rec[1:]
+            reason = (rec[0] if rec else "") or reason
+        except (OSError, ValueError):
             pass
         abandoned.append({"generation": GENERATIONS[gen][0], "reason": reason})
         if rank == 0:
-            log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned: {reason}")
-    return rc
+            log(f"generation {gen} ({GENERATIONS[gen][0]}) abandoned: {reason}" + (f"; skipping to generation {nxt}" if nxt != gen + 1 and nxt < len(GENERATIONS) else ""))
+        gen = max(nxt, gen + 1)
+    return leave(rc)
 
 
 def init_process_group(backend):

@@ -386,7 +386,7 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
 
 /* Coarse solve for the level above: one cycle (V), or two GCR steps preconditioned by the cycle
  * (K-cycle; docs/AGMG_For_Convection_Diffusion.pdf §3.1 — derived from the paper, the reference's
- * C++ has no K-cycle):  x = (α1/ρ1 − γα2/(ρ1ρ2)) c1 + (α2/ρ2) c2,  ρ2 = β − γ²/ρ1. */
+ * C++ has no K-cycle):  x = (α1/ρ1) c1 + (α2/ρ2)(c2 − (γ/ρ1) c1), second direction orthogonalised explicitly (see below). */
 static void coarse_solve_inner(const orc_hier *h, int l, const double *rhs, double *x);
 static void coarse_solve_rec(const orc_hier *h, int l, const double *rhs, double *x) {
   coarse_solve_inner(h, l, rhs, x);
@@ -408,12 +408,22 @@ static void coarse_solve_inner(const orc_hier *h, int l, const double *rhs, doub
   for (int i = 0; i < n; i++) rp[i] = rhs[i] - a * v1[i];
   vcycle_rec(h, l, rp, c2, 1);
   orc_spmv(A, c2, v2);
-  double gamma = orc_dot(n, d2, v1), beta = orc_dot(n, d2, v2), alpha2 = orc_dot(n, d2, rp);
+  /* second direction orthogonalised explicitly: c2' = c2 - g c1, v2' = v2 - g v1 with g = gamma/rho1; rho2 = d2'.v2', alpha2 = d2'.r'.
+   * In exact arithmetic rho2 = beta - gamma^2/rho1 (the paper's formula); formed this way it is not the difference of two nearly equal
+   * numbers when c2 is almost parallel to c1.  x = (alpha1/rho1) c1 + (alpha2/rho2) c2'. */
+  double gamma = orc_dot(n, d2, v1);
+  double g = rho1 != 0.0 ? gamma / rho1 : 0.0;
+  double rho2 = 0.0, alpha2 = 0.0;
+  for (int i = 0; i < n; i++) {
+    double v2o = v2[i] - g * v1[i];
+    double d2o = h->kcycle_energy ? c2[i] - g * c1[i] : v2o;
+    rho2 += d2o * v2o;
+    alpha2 += d2o * rp[i];
+  }
   double k1 = 0.0, k2 = 0.0;
   if (rho1 != 0.0) {
-    double rho2 = beta - gamma * gamma / rho1;
     k1 = alpha1 / rho1;
-    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= gamma * k2 / rho1; }
+    if (rho2 > 0.0) { k2 = alpha2 / rho2; k1 -= (gamma / rho1) * k2; }
   }
   for (int i = 0; i < n; i++) x[i] = k1 * c1[i] + k2 * c2[i];
 }

@@ -51,6 +51,10 @@ def main():
     assert len(sh.plans) >= 2, "test needs at least one sharded coarse level"
     if os.environ.get("MGS_NATIVE_RCCL") == "force":
         assert sh.native, "native transport was requested but the build fell back to callbacks"
+    if os.environ.get("MGS_NATIVE_TRANSPORT") == "p2p":
+        assert sh.native and sh.native_transport == "p2p", "peer-to-peer transport was requested but the build fell back"
+    if os.environ.get("MGS_NATIVE_RCCL") == "0":
+        assert not sh.native
     if not mtx:
         n2 = N * N
     bg = orc.rand_rhs(nglob)
@@ -58,7 +62,7 @@ def main():
     sh.vcycle(b, x)
     x_loc = x.numpy(n_loc)
     graph = None
-    if os.environ.get("MGS_FAKE_RCCL_STREAM") == "1" and sh.native:
+    if (os.environ.get("MGS_FAKE_RCCL_STREAM") == "1" or os.environ.get("MGS_EXPECT_GRAPH") == "1") and sh.native:
         # stream-ordered stand-in: the native cycle is CAPTURED (after two eager runs) with its exchanges, tail all-gather and tail cycle
         # inside the graph, and replayed — same bits as the eager cycle, on every rank
         for _ in range(4):
@@ -121,26 +125,38 @@ def main():
     xr = ho.vcycle(bg)
     err = np.linalg.norm(x_loc - xr[lo * n2: hi * n2]) / np.linalg.norm(xr[lo * n2: hi * n2])
     assert err <= 1e-10, err
-    # K-cycle on the sharded levels: inner products summed over the ranks, against the oracle's K-cycle
+    # K-cycle on the sharded levels: inner products summed over the ranks, against the oracle's K-cycle.  ONE bar for
+    # every grid size: 1e-9.  The energy form (flexible-CG coefficients — the form for this SPD operator) is held to it at every N; the
+    # GCR form (the paper's, for nonsymmetric operators) as well wherever its map is conditioned well enough for ANY two implementations
+    # to agree that closely: on this Poisson operator its first step is tiny, the two directions are nearly parallel, and at 128³ a 1e-16
+    # relative perturbation of the INPUT moves the oracle's own output by 2e-9 (tools/kcycle_cond_cpu.py; tests/test_gpu_parity.py::
+    # test_kcycle_vs_oracle_at_128), so there the device may differ from the oracle by at most 20x what the oracle differs from itself.
     kerr = None
-    # (tolerance: the K-cycle's coefficients are quotients of inner products whose summation order differs between device, shards and oracle; on
-    # large grids the second direction is nearly parallel to the first and that rounding is amplified — the UNSHARDED device K-cycle differs from the
-    # oracle's by 7e-9 … 3e-8 at 128³, `tools/kcycle_diag_gpu.py 128` — so 1e-9 holds for the small grids only)
-    ktol = 1e-9 if N <= 48 else 1e-7
+    ktol = 1e-9
     if len(sh.plans) >= 3 and not mtx:
-        sh.set_kcycle(1); ho.set_kcycle(1)
-        xk = ctx.vec(n_ext); sh.vcycle(b, xk)
-        xkr = ho.vcycle(bg)
-        kerr = np.linalg.norm(xk.numpy(n_loc) - xkr[lo * n2: hi * n2]) / np.linalg.norm(xkr[lo * n2: hi * n2])
-        assert kerr <= ktol, kerr
+        sl = slice(lo * n2, hi * n2)
+        kdeep = len(sh.plans) + 1      # K levels reaching past the last sharded level: that level (the replicated tail's entry level) gets its two Krylov steps too
+        ctx.set_option("kcycle_energy", 1); ho.set_kcycle_energy(1)
+        for kl in (1, kdeep):
+            sh.set_kcycle(kl); ho.set_kcycle(kl)
+            xk = ctx.vec(n_ext); sh.vcycle(b, xk)
+            xkr = ho.vcycle(bg)
+            e = np.linalg.norm(xk.numpy(n_loc) - xkr[sl]) / np.linalg.norm(xkr[sl])
+            assert e <= ktol, ("K-cycle, energy form", kl, e)
+            kerr = e if kerr is None else max(kerr, e)
         assert np.linalg.norm(xk.numpy(n_loc) - x_loc) > 1e-6 * np.linalg.norm(x_loc), "K-cycle did not change the cycle"
-        # K levels reaching past the last sharded level: that level (the replicated tail's entry level) gets its two Krylov steps too
-        kdeep = len(sh.plans) + 1
-        sh.set_kcycle(kdeep); ho.set_kcycle(kdeep)
-        xk2 = ctx.vec(n_ext); sh.vcycle(b, xk2)
-        xk2r = ho.vcycle(bg)
-        kerr2 = np.linalg.norm(xk2.numpy(n_loc) - xk2r[lo * n2: hi * n2]) / np.linalg.norm(xk2r[lo * n2: hi * n2])
-        assert kerr2 <= ktol, ("K-cycle through the replicated tail", kerr2)
+        ctx.set_option("kcycle_energy", 0); ho.set_kcycle_energy(0)
+        for kl in (1, kdeep):
+            sh.set_kcycle(kl); ho.set_kcycle(kl)
+            xk = ctx.vec(n_ext); sh.vcycle(b, xk)
+            xkr = ho.vcycle(bg)
+            e = np.linalg.norm(xk.numpy(n_loc) - xkr[sl]) / np.linalg.norm(xkr[sl])
+            bar = ktol
+            if e > ktol and N > 48:          # conditioning of the map itself, measured on the oracle (identical on every rank: same seed)
+                pert = bg * (1.0 + 1e-16 * np.random.default_rng(5).standard_normal(bg.size))
+                sens = np.linalg.norm(ho.vcycle(pert) - xkr) / np.linalg.norm(xkr)
+                bar = max(ktol, 20.0 * sens)
+            assert e <= bar, ("K-cycle, GCR form" + (" through the replicated tail" if kl == kdeep else ""), kl, e, bar)
         sh.set_kcycle(0); ho.set_kcycle(0)
     # preconditioned solve across shards (dots all-reduced), true residual checked globally
     xsol = ctx.vec(n_ext)

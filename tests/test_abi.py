@@ -216,4 +216,6 @@ def test_device_allocations_go_through_the_arena_entry_points():
         n = sum(1 for line in open(f) if pat.search(line) and not line.lstrip().startswith("//") and "mgs_fail(" not in line)
         if n:
             raw[os.path.basename(f)] = n
-    assert raw == {"mgs_api.hip": 3}, raw
+    # comm_p2p.hip: the peer-to-peer window is an allocation of its own by necessity (hipIpcGetMemHandle names whole allocations, and the window is
+    # uncached memory: hipExtMallocWithFlags) — its one hipFree is the only raw call outside the arena's entry points
+    assert raw == {"mgs_api.hip": 3, "comm_p2p.hip": 1}, raw

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     """callback transport (torch.distributed / gloo, halo buffers staged through the host), 2-4 ranks on this one GPU, against the oracle's cycle on
     the globally assembled hierarchy; the worker also checks Galerkin products, K-cycles and a solve to 1e-10"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="0")     # callbacks only (a native transport would take over otherwise)
     if N >= 100:
         env["MGS_OPTIONS"] = "split_min_rows=400000"      # the worker leaves the interior/boundary split threshold alone when the option is given
     port = 29600 + (os.getpid() % 1000) + world
@@ -29,14 +29,17 @@ def test_sharded_vcycle_matches_oracle(world, N, tail, overlap, fused):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 700, 0), (3, 36, 500, 0), (2, 40, 700, 1)])
+@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 700, 0), (3, 36, 500, 0), (2, 40, 700, 1), (2, 40, 700, 2), (3, 36, 500, 2)])
 def test_kcycle_on_row_shards(world, N, tail, native):
-    """K-cycle on sharded levels: the five inner products of the two GCR steps summed over the ranks (callback transport: host
-    all-reduce; native transport: ncclAllReduce of the stand-in) — one K-cycle application vs the oracle's K-cycle (≤1e-9)"""
+    """K-cycle on sharded levels: the inner products of the two Krylov steps summed over the ranks (callback transport: host
+    all-reduce; native 1: ncclAllReduce of the stand-in; native 2: the peer-to-peer transport's rank-ordered sum) — K-cycle
+    applications vs the oracle's K-cycle (≤1e-9, energy form at every size)"""
     fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    if native:
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="0")
+    if native == 1:
         env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    elif native == 2:
+        env.update(MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p")
     port = 29850 + (os.getpid() % 1000) + world + 10 * native
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
@@ -44,15 +47,17 @@ def test_kcycle_on_row_shards(world, N, tail, native):
     assert r.returncode == 0 and "DIST_OK" in r.stdout and "kcycle_err=" in r.stdout and "kcycle_err=None" not in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 3000, 0), (3, 36, 2000, 0), (2, 40, 3000, 1), (3, 36, 2000, 1)])
+@pytest.mark.parametrize("world,N,tail,native", [(2, 40, 3000, 0), (3, 36, 2000, 0), (2, 40, 3000, 1), (3, 36, 2000, 1), (3, 36, 2000, 2)])
 def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
     """the grouped pre pass (restriction inside the pre pass, t-form post pass) on row shards — halo payload exchanged first, halo-tagged
     pattern codes — forced onto these small grids (group_min_blocks=1, 60 % strays allowed); callback transport and native transport
     (stand-in RCCL); cycle vs the oracle, solve to 1e-10"""
     fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_OPTIONS="group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000")
-    if native:
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_OPTIONS="group_min_blocks=1,group_stray_pct=60,split_min_rows=100000000", MGS_NATIVE_RCCL="0")
+    if native == 1:
         env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    elif native == 2:      # peer-to-peer transport (csrc/comm_p2p.hip)
+        env.update(MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p")
     port = 29750 + (os.getpid() % 1000) + world + 10 * native
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
@@ -65,19 +70,26 @@ def test_grouped_pre_pass_on_row_shards(world, N, tail, native):
                                                   # 128³ on four ranks (524 288 rows each): the thresholds of the product decide the forms, as in the N-GPU run —
                                                   # grouped pre pass with halo columns, strip-major block map, pack-free range sends, zoned shard aggregation
                                                   (4, 128, 40000, "split_min_rows=400000")])
-def test_native_cycle_captured_in_a_graph_multi_rank(world, N, tail, opts):
+@pytest.mark.parametrize("transport", ["rccl-stand-in", "p2p"])
+def test_native_cycle_captured_in_a_graph_multi_rank(world, N, tail, opts, transport):
     """The DEFAULT multi-GPU path — native transport with the whole cycle (exchanges, tail all-gather, tail cycle, K-cycle scalars
     summed over the ranks) captured in one hipGraph — with several ranks on this one GPU: tests/fake_rccl in its stream-ordered mode
     (device→pinned copy, host function moving the bytes through files, pinned→device copy: capturable like RCCL's kernels).  Asserts
     in the worker: capture after two eager cycles, replay == eager bit for bit, more (rhs, out) pairs than cache slots, cycle vs the
-    oracle, K-cycle vs the oracle (tail 700: three sharded levels), solve to 1e-10."""
+    oracle, K-cycle vs the oracle (tail 700: three sharded levels), solve to 1e-10.
+    transport "p2p": the product's own peer-to-peer transport (csrc/comm_p2p.hip) — the ranks' processes map each other's device windows
+    (hipIpcOpenMemHandle) and every exchange, the tail's all-gather and the all-reduces are ONE kernel each, captured like any other;
+    the setup cross-checks its exchanges against torch.distributed (gloo) bit for bit, the worker the cycle against the oracle."""
     fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(fake):
         subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_FAKE_RCCL_STREAM="1")
+    if transport == "p2p":
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p", MGS_EXPECT_GRAPH="1")
+    else:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_FAKE_RCCL_STREAM="1")
     if opts:
         env["MGS_OPTIONS"] = opts
-    port = 29950 + (os.getpid() % 1000) + world + (7 if opts else 0) + (3 if tail == 700 else 0)
+    port = 29950 + (os.getpid() % 1000) + world + (7 if opts else 0) + (3 if tail == 700 else 0) + (40 if transport == "p2p" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
@@ -101,14 +113,17 @@ def test_native_transport_multi_rank_matches_oracle(world, N, tail):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
 
 
-@pytest.mark.parametrize("world,native", [(2, 0), (3, 0), (2, 1), (3, 2)])
+@pytest.mark.parametrize("world,native", [(2, 0), (3, 0), (2, 1), (3, 2), (3, 3)])
 def test_sharded_general_operator_matches_oracle(world, native, inputs):
     """a bundled, nonsymmetric operator (CSky3d30) sharded by contiguous row ranges with the generic halo plan
     (shard_from_global): sharded cycle vs the oracle on the globally assembled hierarchy, sharded solve to 1e-10.
     native 1: the native transport on the stand-in RCCL (send lists that are NOT plane ranges: packed or multi-range exchanges,
-    zones over irregular lists, halo of the tail level from the replicated solution); 2: the same, stream-ordered and captured."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    if native:
+    zones over irregular lists, halo of the tail level from the replicated solution); 2: the same, stream-ordered and captured;
+    3: the peer-to-peer transport (captured)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="0")
+    if native == 3:
+        env.update(MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p", MGS_EXPECT_GRAPH="1")
+    elif native:
         env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so"))
         if native == 2:
             env["MGS_FAKE_RCCL_STREAM"] = "1"
@@ -142,3 +157,17 @@ def test_rccl_transport_on_library_memory_world1():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "nccl_world1_worker.py")], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
     assert r.returncode == 0 and "NCCL_W1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_native_transports_same_bits_rank_of_8_at_256():
+    """tools/emulate_rank.py as a test (round-3 hygiene item): a MIDDLE rank of 8 of the 256^3 problem (2.1 M rows, every level above the product's
+    own thresholds: grouped pre pass with halo columns, pack-free range sends, zoned aggregation, tail halo fill), exchanging both halo
+    planes with itself at world 1 over REAL RCCL (backend nccl) and over the peer-to-peer transport, the whole cycle captured in a
+    hipGraph and replayed: the captured cycle's result has the same bits on both transports."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29200 + os.getpid() % 90), RANK="0", WORLD_SIZE="1", EMU_ONE="1", EMU_REPS="10",
+               EMU_TRANSPORTS="p2p,rccl")
+    for k in ("MGS_NATIVE_RCCL", "MGS_NATIVE_TRANSPORT", "MGS_OPTIONS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emulate_rank.py"), "256", "8", "100000"], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "EMU_OK" in r.stdout and r.stdout.count("captured_cycles") >= 2, r.stdout[-3000:] + r.stderr[-6000:]
+    assert "transport=p2p" in r.stdout and "transport=rccl" in r.stdout

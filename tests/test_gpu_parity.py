@@ -858,6 +858,145 @@ def test_kcycle_vs_oracle(ctx, mg, orc):
     h.set_kcycle(0)
 
 
+def _oracle_hierarchy(h, orc, A0=None, omega=0.6):
+    """the hierarchy the device built, downloaded once, as an oracle hierarchy (operators and aggregate maps bit for bit)"""
+    import scipy.sparse as sps
+    As, Ps = [], []
+    for l in range(h.nlev):
+        rp, ci, v = h.level_A(l).download(); r = h.level_shape(l)[0]
+        As.append(A0 if (l == 0 and A0 is not None) else orc.Csr.from_arrays(r, r, rp, ci, v))
+        if l < h.nlev - 1:
+            T = h.level_P(l); a = T.agg(); nf, nc = T.shape; rr = np.nonzero(a >= 0)[0]
+            Ps.append(orc.Csr.from_scipy(sps.csr_matrix((np.ones(rr.size), (rr, a[rr])), shape=(nf, nc))))
+    return orc.Hier(As[0], Ps, omega=omega, nu1=1, nu2=1, As=As), As
+
+
+def test_kcycle_vs_oracle_at_128(ctx, mg, orc):
+    """The K-cycle against the oracle at 128^3 (2.1 M rows, the size the round-3 multi-rank run went red at), ONE bar for every size: 1e-9.
+    * energy form (the form for SPD operators, used on this Poisson operator by bench.py) on K = 1 and K = 4 levels;
+    * GCR form (the paper's, for nonsymmetric operators) on the nonsymmetric convection-diffusion stand-in at 64^3.
+    The second Krylov direction is orthogonalised explicitly (no rho2 = beta - gamma^2/rho1), on the device and in the oracle.
+    The GCR form on the POISSON operator is a badly conditioned map whatever the arithmetic — its first step is tiny (alpha1/rho1 = 0.02), so
+    c2 = B(r - 0.02 v1) is almost c1 and x = k1 c1 + k2 c2 has k1 = -32.6, k2 = 33.3: a 1e-16 relative perturbation of the INPUT moves the oracle's
+    own output by 2e-9 at 128^3 (tools/kcycle_cond_cpu.py 128 0 8; 4e-16 for the energy form).  It is therefore compared against the oracle's
+    measured sensitivity, not against a fixed number: the device may differ from the oracle by at most 20x what the oracle differs from itself
+    under a one-ulp-sized input perturbation."""
+    N = 128; n = N ** 3
+    A = ctx.poisson3d(N)
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
+    assert h.nlev >= 6
+    ho, As = _oracle_hierarchy(h, orc)
+    b = ctx.vec(n).rand(seed=7); b_np = b.numpy()
+    assert rel(h.vcycle(b).numpy(), ho.vcycle(b_np)) <= 1e-12
+    ctx.set_option("kcycle_energy", 1); ho.set_kcycle_energy(1)
+    try:
+        for kl in (1, 4):
+            h.set_kcycle(kl); ho.set_kcycle(kl)
+            e = rel(h.vcycle(b).numpy(), ho.vcycle(b_np))
+            assert e <= 1e-9, ("energy form", kl, e)
+    finally:
+        ctx.set_option("kcycle_energy", 0); ho.set_kcycle_energy(0)
+    # GCR form on this SPD operator: conditioning-aware bar (see the docstring)
+    h.set_kcycle(4); ho.set_kcycle(4)
+    xo = ho.vcycle(b_np)
+    pert = b_np * (1.0 + 1e-16 * np.random.default_rng(1).standard_normal(n))
+    sens = rel(ho.vcycle(pert), xo)
+    e = rel(h.vcycle(b).numpy(), xo)
+    assert e <= max(1e-9, 20.0 * sens), ("GCR form on Poisson", e, sens)
+    h.set_kcycle(0)
+    del h, A, ho, As
+    # GCR form where it belongs: nonsymmetric convection-diffusion (stand-in of the reference's CSky/matvf class), 64^3
+    from multigridsolver_amd.synthetic import convdiff3d
+    Nc = 64; nc = Nc ** 3
+    rp, ci, v = convdiff3d(Nc)
+    Ac = ctx.csr(nc, nc, rp, ci, v)
+    hc = mg.Hierarchy(Ac, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
+    assert hc.nlev >= 3
+    hco, _ = _oracle_hierarchy(hc, orc)
+    bc = ctx.vec(nc).rand(seed=8); bc_np = bc.numpy()
+    assert rel(hc.vcycle(bc).numpy(), hco.vcycle(bc_np)) <= 1e-10
+    for kl in (1, hc.nlev - 2):
+        hc.set_kcycle(kl); hco.set_kcycle(kl)
+        e = rel(hc.vcycle(bc).numpy(), hco.vcycle(bc_np))
+        assert e <= 1e-9, ("GCR form, convection-diffusion", kl, e)
+    hc.set_kcycle(0)
+
+
+def test_strip_map_options_with_far_bands(ctx, mg, orc):
+    """strip-major workgroup map with small strips (advisor, round 3): strip = 1 made the multiply-high constant wrap (2^32/1 + 1 = 1), row blocks
+    were visited twice / skipped on operators whose far band spans >= 512 row blocks.  A 370 x 370 x 18 seven-point grid has the band (136 900
+    rows = 535 blocks) and enough blocks per XCD (>= 2 bands) at 2.5 M rows; every strip setting must give the bits of the plain map."""
+    import scipy.sparse as sps
+    nx, nz = 370, 18
+    ex = sps.diags([-np.ones(nx - 1), 2 * np.ones(nx), -np.ones(nx - 1)], [-1, 0, 1])
+    ez = sps.diags([-np.ones(nz - 1), 2 * np.ones(nz), -np.ones(nz - 1)], [-1, 0, 1])
+    I = sps.identity
+    M = (sps.kron(sps.kron(ez, I(nx)), I(nx)) + sps.kron(sps.kron(I(nz), ex), I(nx)) + sps.kron(sps.kron(I(nz), I(nx)), ex)).tocsr()
+    M.sort_indices()
+    n = M.shape[0]
+    A = ctx.csr(n, n, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data)
+    assert A.plan_info()["far_band"] >= 512 * 256
+    x = ctx.vec(n).rand(seed=3); b = ctx.vec(n).rand(seed=4)
+    ref_y = M @ x.numpy()
+    try:
+        ctx.set_option("strip", 0)
+        y0 = A.spmv(x).numpy(); r0 = A.residual(x, b).numpy()
+        assert np.linalg.norm(y0 - ref_y) <= 1e-14 * np.linalg.norm(ref_y)
+        h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
+        c0 = h.vcycle(b).numpy()
+        for opt, val in (("strip", 1), ("strip", 2), ("strip", 3), ("strip", 7), ("strip", -1), ("group_strip", 1), ("group_strip", 5)):
+            ctx.set_option("strip", -1); ctx.set_option("group_strip", 0)
+            ctx.set_option(opt, val)
+            assert np.array_equal(A.spmv(x).numpy(), y0), (opt, val)
+            assert np.array_equal(A.residual(x, b).numpy(), r0), (opt, val)
+            assert np.array_equal(h.vcycle(b).numpy(), c0), (opt, val)
+    finally:
+        ctx.set_option("strip", -1); ctx.set_option("group_strip", 0)
+
+
+def test_fgcr_fused_passes(ctx, mg, orc):
+    """mgs_fgcr with its fused passes (multi-dot, multi-update, directions combined once per window through the triangular coefficient system)
+    against a numpy restatement of flexible GCR(m) with the SAME linear preconditioner (the V-cycle): same iteration count, same iterates to
+    1e-8, restart windows of 3 (several window closures), 10 and 20 (more vectors than one multi-vector pass takes)."""
+    N = 24; n = N ** 3
+    A = ctx.poisson3d(N); Ao = orc.poisson3d(N); Asp = Ao.to_scipy().tocsr()
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 60, 10).finalize()
+    b_np = orc.rand_rhs(n); b = ctx.vec(b_np)
+    nb = np.linalg.norm(b_np)
+
+    def prec(v):
+        return h.vcycle(ctx.vec(v)).numpy()
+
+    def fgcr_np(m, tol, maxit):
+        x = np.zeros(n); r = b_np.copy(); it = 0
+        while it < maxit:
+            Cs, Vs, rh = [], [], []
+            for k in range(m):
+                c = prec(r); v = Asp @ c
+                hs = [(vj @ v) / rj for vj, rj in zip(Vs, rh)]            # classical Gram-Schmidt, as the device
+                for bj, cj, vj in zip(hs, Cs, Vs):
+                    v = v - bj * vj; c = c - bj * cj
+                rho = v @ v; al = (v @ r) / rho
+                x = x + al * c; r = r - al * v
+                Cs.append(c); Vs.append(v); rh.append(rho); it += 1
+                if np.linalg.norm(r) / nb < tol or it >= maxit:
+                    break
+            r = b_np - Asp @ x
+            if np.linalg.norm(r) / nb < tol:
+                return it, x
+        return it, x
+
+    for m in (3, 10, 20):
+        itn, xn = fgcr_np(m, 1e-10, 300)
+        x = ctx.vec(n); st, it, tol = mg.fgcr(A, x, b, h, m, 300, 1e-10)
+        assert st == 0 and abs(it - itn) <= 1, (m, it, itn)
+        assert np.linalg.norm(b_np - Asp @ x.numpy()) / nb <= 1.01e-10
+        assert rel(x.numpy(), xn) <= 1e-8, (m, rel(x.numpy(), xn))
+    # unpreconditioned, iteration limit inside a window: status 1 and the TRUE residual reported
+    x = ctx.vec(n); st, it, tol = mg.fgcr(A, x, b, None, 10, 7, 1e-12)
+    assert st == 1 and it == 7 and abs(tol - np.linalg.norm(b_np - Asp @ x.numpy()) / nb) <= 1e-12
+
+
 def test_random_matrices_vs_oracle(ctx, mg, orc):
     """seeded random sparse operators (rectangular, empty rows, skewed row lengths): every SpMV-shaped
     kernel against the oracle; bit-exact when no row exceeds the sequential-path limit."""

@@ -23,7 +23,7 @@ def _run(cmd, extra_env=None, timeout=300):
     return r, [json.loads(l) for l in lines]
 
 
-@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (2, "exit"), (1, "hang"), (0, "crash_after_done"), (0, "die_before_print")])
+@pytest.mark.parametrize("ok_from,mode", [(0, "exit"), (3, "exit"), (1, "hang"), (0, "crash_after_done"), (0, "die_before_print")])
 def test_spawn_ranks_generations(ok_from, mode):
     r, out = _run([sys.executable, DUMMY, str(ok_from), mode, "2"], {"MGS_BENCH_WATCHDOG_S": "4"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -33,8 +33,8 @@ def test_spawn_ranks_generations(ok_from, mode):
     assert all(a["reason"] for a in out[0]["abandoned_generations"])
     if ok_from == 0:
         assert out[0]["native"] == "1" and out[0]["graph"] == "1"
-    if ok_from == 2:
-        assert out[0]["native"] == "0"
+    if ok_from == 3:
+        assert out[0]["native"] == "0" and out[0]["name"] == "torch.distributed-callbacks"
 
 
 def test_spawn_ranks_gives_up_with_the_workers_code():
@@ -67,13 +67,47 @@ def test_supervisors_change_generation_together():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert len(out) == 1 and out[0]["generation"] == 1 and out[0]["sum"] == 1.0, out
     assert dt < 90, f"generation change waited for a watchdog ({dt:.0f} s)"
-    assert out[0]["abandoned_generations"][0]["generation"] == "native-rccl+graph" and "exited with" in out[0]["abandoned_generations"][0]["reason"]
+    assert out[0]["abandoned_generations"][0]["generation"] == "native-p2p+graph" and "exited with" in out[0]["abandoned_generations"][0]["reason"]
 
 
 def test_first_generation_honours_explicit_choices():
     from multigridsolver_amd import launch
+    names = [g[0] for g in launch.GENERATIONS]
+    assert names == ["native-p2p+graph", "native-rccl+graph", "native-rccl", "torch.distributed-callbacks", "gloo-host-staged"]
     assert launch.first_generation({}) == 0
-    assert launch.first_generation({"MGS_NATIVE_GRAPH": "0"}) == 1
-    assert launch.first_generation({"MGS_NATIVE_RCCL": "0"}) == 2
-    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo"}) == 3
-    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo", "MGS_NATIVE_RCCL": "force"}) == 1
+    assert launch.first_generation({"MGS_NATIVE_TRANSPORT": "rccl"}) == 1
+    assert launch.first_generation({"MGS_NATIVE_GRAPH": "0"}) == 2
+    assert launch.first_generation({"MGS_NATIVE_RCCL": "0"}) == 3
+    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo"}) == 4
+    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo", "MGS_NATIVE_RCCL": "force"}) == 2
+    # the RCCL generations run in their conservative form (one packed message per peer) unless the caller says otherwise
+    assert launch.GENERATIONS[1][1]["MGS_NATIVE_SEGMENTS"] == "0"
+    assert launch._worker_env({"MGS_NATIVE_SEGMENTS": "1"}, 1, 0, 0, 2, "127.0.0.1", 1, "/tmp/x")["MGS_NATIVE_SEGMENTS"] == "1"
+
+
+@pytest.mark.parametrize("launcher", ["spawn", "torchrun"])
+def test_time_budget_skips_to_the_last_generation(launcher):
+    """once the run's time budget is spent (here: 0 s) a failed generation is followed by the LAST one, on every rank together —
+    the driver's bench limit must not be eaten by generation after generation"""
+    port = 29300 + ((os.getpid() + 123) % 500)
+    cmd = [sys.executable, DUMMY, "4", "exit", "2"] if launcher == "spawn" else \
+          [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), DUMMY, "4", "exit", "2"]
+    r, out = _run(cmd, {"MGS_BENCH_WATCHDOG_S": "4", "MGS_BENCH_BUDGET_S": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(out) == 1 and out[0]["generation"] == 4 and out[0]["name"] == "gloo-host-staged", out
+    assert [a["generation"] for a in out[0]["abandoned_generations"]] == ["native-p2p+graph"], out
+
+
+def test_run_directory_is_unique_and_removed():
+    """the supervisors' shared directory is named after the launcher's pid AND start time (a recycled pid/port pair of an earlier run cannot
+    collide) and is gone after a successful run"""
+    import glob
+    import tempfile
+    from multigridsolver_amd import launch
+    assert launch._proc_start(os.getpid()) > 0
+    port = 29300 + ((os.getpid() + 321) % 500)
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), f"mgs_bench_{port}_*")))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), DUMMY, "1", "exit", "2"]
+    r, out = _run(cmd, {"MGS_BENCH_WATCHDOG_S": "4"})
+    assert r.returncode == 0 and len(out) == 1 and out[0]["generation"] == 1, r.stderr[-3000:]
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), f"mgs_bench_{port}_*"))) == before

@@ -3,7 +3,9 @@
 planes [lo, hi) of the grid^3 operator and exchanges both halo planes WITH ITSELF through the same callbacks, pack
 kernels and all_to_all calls the real run uses (numerically a periodic wrap of the slab — timing only).  Gives the
 per-GPU cycle time including host/launch/collective-call overhead; link latency and the full-size replicated tail
-are not in it.  usage: emulate_rank.py [grid=512] [ranks=8] [tail_rows=100000]"""
+are not in it.  usage: emulate_rank.py [grid=512] [ranks=8] [tail_rows=100000]
+env: EMU_ONE=1 native configurations only; EMU_TRANSPORTS=p2p,rccl (default) the native transports to run, one after the other — the
+cycle's result must have the SAME BITS on every transport (asserted; exit code 1 otherwise)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +18,7 @@ from multigridsolver_amd import dist as mgd
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 tail_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
-dist.init_process_group("nccl")
+dist.init_process_group(os.environ.get("EMU_BACKEND", "nccl"))
 torch.cuda.set_device(0)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 ctx = mg.Context(0, stream.cuda_stream)
@@ -33,8 +35,14 @@ else:                 # two ranks: rank 1 has a lower neighbour only
     ids = np.arange(n_loc - n2, n_loc).astype(np.int32)
 assert A.shape[1] - A.shape[0] == ids.size, "emulated plan does not fit the slab"
 plan = mgd.LevelPlan(n_loc, [ids], [ids])
-configs = ((True, True, True),) if os.environ.get("EMU_ONE") else ((True, True, True), (True, True, False), (False, True, False), (True, False, False))
-for overlap, fused, native in configs:
+transports = [t for t in os.environ.get("EMU_TRANSPORTS", "p2p,rccl").split(",") if t]
+configs = [(True, True, True, t) for t in transports]
+if not os.environ.get("EMU_ONE"):
+    configs += [(True, True, False, None), (False, True, False, None), (True, False, False, None)]
+bits_differ = False
+for overlap, fused, native, transport in configs:
+    if transport:
+        os.environ["MGS_NATIVE_TRANSPORT"] = transport
     sh = mgd.ShardedHierarchy(ctx, A, plan, 0.6, 1, 1, comm)
     t0 = time.perf_counter()
     sh.build(10.0, 2, 8.0, tail_rows=tail_rows, coarse_rows=2500, overlap=overlap, fused=fused, native=native, log=print)
@@ -47,8 +55,12 @@ for overlap, fused, native in configs:
             ctx.sync(); print("  cycle", i, sh.h.graph_info(), mg.lib().mgs_last_error(ctx.h), flush=True)
     ctx.sync(); torch.cuda.synchronize()
     xn = x.numpy(n_loc)
+    if native:
+        assert sh.native and sh.native_transport == transport, f"transport {transport} was not installed"
     if fused:
         if "ref" in globals():
+            if native and not np.array_equal(xn, ref):
+                bits_differ = True
             print("   same bits as the first configuration:", bool(np.array_equal(xn, ref)),
                   f"(relative difference {np.linalg.norm(xn - ref) / np.linalg.norm(ref):.2e}; the grouped t-form and the r/b form of the cycle agree to rounding, not bit for bit)", flush=True)
         else:
@@ -61,7 +73,7 @@ for overlap, fused, native in configs:
     t_host = time.perf_counter() - t0          # time to ENQUEUE the cycles (host side)
     ctx.sync(); torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    print(f"native={int(sh.native)} overlap={int(overlap)} fused={int(fused)}: sharded levels {[p.n_loc for p in sh.plans]} (+tail {sh.tail.nlev} levels), setup {t_setup:.2f} s, "
+    print(f"native={int(sh.native)} transport={getattr(sh, 'native_transport', None)} overlap={int(overlap)} fused={int(fused)}: sharded levels {[p.n_loc for p in sh.plans]} (+tail {sh.tail.nlev} levels), setup {t_setup:.2f} s, "
           f"{t_all / reps * 1e3:.3f} ms per cycle (host enqueue {t_host / reps * 1e3:.3f} ms), {(sh.n_exchanges - ex0) / reps:.0f} exchanges per cycle; "
           f"level-0 form {sh.h.fused_info(0)}; graph {sh.h.graph_info()}", flush=True)
     sh.close()
@@ -69,3 +81,7 @@ for overlap, fused, native in configs:
 # the same slab as an unsharded-size reference: one GPU's share of the work without any exchange
 ctx.close()
 dist.destroy_process_group()
+if bits_differ:
+    print("TRANSPORTS DISAGREE", flush=True)
+    sys.exit(1)
+print("EMU_OK", flush=True)
