@@ -61,14 +61,25 @@ def pmc_traffic(kernel="spmv", grid=512):
     return None
 
 
+def kernel_source_sha():
+    """identity of the row-block kernels' source (csrc/kernels_spmv.hip): a PMC summary applies to this build only if it was taken on the same text"""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(REPO, "multigridsolver_amd", "csrc", "kernels_spmv.hip"), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_summary(grid=512):
-    """newest committed profile summary for this grid: (dict, file name) or None"""
+    """newest committed profile summary for this grid THAT WAS TAKEN ON THIS BUILD'S KERNEL SOURCE (its `kernel_source_sha` equals
+    kernel_source_sha(); the GPU box has no git history to ask): (dict, file name) or None — a summary of older kernels never mixes its
+    bytes with this run's times (advisor, round 3)"""
     import glob
-    best = None
+    best, sha = None, kernel_source_sha()
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
-            if d.get("grid") == grid and d.get("fine_level_kernels"):
+            if d.get("grid") == grid and d.get("fine_level_kernels") and sha and d.get("kernel_source_sha") == sha:
                 best = (d, os.path.basename(f))
         except Exception:  # noqa: BLE001
             pass
@@ -151,6 +162,76 @@ def bundled_cases(mg, args):
     return out
 
 
+def convdiff_leg(mg, args, N=256):
+    """The reference's own problem class at scale (VERDICT r3 items 4 and Weak #6): the nonsymmetric, variable-coefficient convection-diffusion
+    family of its bundled `matrices/CSky3d30.mtx` (multigridsolver_amd/synthetic.py `csky3d`: constant strong upwind convection, periodic cubes
+    of 1e3..9e3 times the background diffusion; modelled on the bundled file, 94 % of whose entries it reproduces at N = 30 — the 80^3 member
+    the reference names is absent from its checkout), N^3 rows built on the host and uploaded once.  Untimed region of the bench: kernel and
+    cycle time per million rows beside the constant-coefficient Poisson figures, and BiCGSTAB + V-cycle against FGCR(10) + K-cycle in the
+    paper's GCR form on the levels a row-sharded run keeps sharded (>= 600 k rows: the paper's setting, W-cycle cost while the coarsening
+    ratio stays near 4), three right-hand sides, true residuals recomputed."""
+    from multigridsolver_amd.synthetic import csky3d
+    t0 = time.perf_counter()
+    rp, ci, v = csky3d(N)
+    t_gen = time.perf_counter() - t0
+    n = N ** 3
+    ctx = mg.Context(0)
+    try:
+        A = ctx.csr(n, n, rp, ci, v)
+        nnz = A.nnz
+        del rp, ci, v
+        t0 = time.perf_counter()
+        h = mg.Hierarchy(A, args.omega, args.nu1, args.nu2).coarsen(args.ktg, args.npass, args.tou, args.coarse_rows, 32).finalize()
+        ctx.sync(); t_setup = time.perf_counter() - t0
+        levels = [h.level_shape(l) for l in range(h.nlev)]
+        b = ctx.vec(n).rand(seed=0); x = ctx.vec(n); xs = ctx.vec(n).rand(seed=1); y = ctx.vec(n)
+        A.optimize()
+        code = A.rowcode_info()
+        A.time_kernel(mg.OP_SPMV, xs, out=y, reps=3)
+        ms_spmv = A.time_kernel(mg.OP_SPMV, xs, out=y, reps=20)
+        for _ in range(3):
+            h.vcycle(b, x)
+        ms_cycle = h.time_vcycle(b, x, reps=20)
+        runs = []
+        klev = max(1, sum(1 for l in range(1, h.nlev - 1) if levels[l][0] >= 600000))
+        for seed in (0, 1, 2):
+            bk = b if seed == 0 else ctx.vec(n).rand(seed=100 + seed)
+            nb = bk.nrm2()
+            xk = ctx.vec(n); ctx.sync(); t0 = time.perf_counter()
+            st, it, tol = mg.bicgstab(A, xk, bk, h, 1000, 1e-10)
+            t_b = time.perf_counter() - t0
+            true_b = A.residual(xk, bk).nrm2() / nb
+            h.set_kcycle(klev)
+            xk.fill(0.0); ctx.sync(); t0 = time.perf_counter()
+            stk, itk, tolk = mg.fgcr(A, xk, bk, h, 10, 1000, 1e-10)
+            t_k = time.perf_counter() - t0
+            true_k = A.residual(xk, bk).nrm2() / nb
+            h.set_kcycle(0)
+            runs.append({"rhs_seed": seed,
+                         "bicgstab_vcycle": {"status": st, "iterations": it, "seconds": t_b, "true_residual": true_b},
+                         "fgcr10_kcycle_gcr": {"status": stk, "iterations": itk, "seconds": t_k, "true_residual": true_k}})
+            del xk
+        h.set_kcycle(klev)
+        ms_kcycle = h.time_vcycle(b, x, reps=5)
+        h.set_kcycle(0)
+        out = {"operator": f"csky3d_{N}^3 (nonsymmetric upwind convection-diffusion of the reference's CSky3d family: v = (1000,1000,1000), diffusion cubes 1e3..9e3; "
+                           "modelled on the bundled CSky3d30.mtx, host-built, uploaded once)",
+               "rows": n, "nnz": nnz, "levels": levels, "host_generation_seconds": t_gen, "setup_seconds": t_setup,
+               "coded_row_blocks": code["coded_blocks"], "row_blocks": code["blocks"],
+               "spmv_ms": ms_spmv, "spmv_us_per_million_rows": ms_spmv * 1e3 / (n / 1e6), "spmv_effective_csr_gbps": spmv_bytes(n, nnz) / (ms_spmv * 1e-3) / 1e9,
+               "vcycle_ms": ms_cycle, "vcycle_us_per_million_rows": ms_cycle * 1e3 / (n / 1e6),
+               "kcycle_levels": klev, "kcycle_ms": ms_kcycle, "runs": runs,
+               "note": "K-cycle in the paper's GCR form (nonsymmetric operator: the energy form of the Poisson leg is for SPD operators only) on the levels of >= 600 k rows; "
+                       "K on ALL levels costs 2^level visits where the coarsening ratio drops below 2 (128^3, 8 K levels: 34 FGCR iterations but 55 ms per cycle against "
+                       "70 BiCGSTAB iterations of a 0.41 ms V-cycle, tools/convdiff_scan.py).  Cycle-vs-oracle parity on nonsymmetric operators: "
+                       "tests/test_gpu_parity.py::test_kcycle_vs_oracle_at_128 and ::test_c4_shaped_standin_three_level_vcycle, bundled CSky operators in "
+                       "::test_bundled_operators_vs_reference_golden"}
+        del h, A, b, x, xs, y
+        return out
+    finally:
+        ctx.close()
+
+
 def _oracle_sample(mg, orc, args, Ns, min_cycles, min_seconds, keep_fine=False):
     """one CPU sample: the hierarchy the device builds for the Ns^3 grid, downloaded once, the oracle's cycle timed on it
     (1 thread) and compared with the GPU cycle on the same right-hand side"""
@@ -178,10 +259,25 @@ def _oracle_sample(mg, orc, args, Ns, min_cycles, min_seconds, keep_fine=False):
         while reps < min_cycles or time.perf_counter() - t0 < min_seconds:
             x = ho.vcycle(b); reps += 1
         t_cycle = (time.perf_counter() - t0) / reps
+        # the same cycle with the oracle's row loops on the host cores this job may use (rows are independent: same bits, checked below)
+        nthr = max(1, min(int(os.environ.get("MGS_CPU_THREADS", "64")), len(os.sched_getaffinity(0))))
+        t_all, x_all = None, None
+        if nthr > 1:
+            try:
+                nthr = orc.set_threads(nthr)
+                ho.vcycle(b)                    # thread team start-up
+                r2, t0 = 0, time.perf_counter()
+                while r2 < min_cycles or time.perf_counter() - t0 < min_seconds / 2:
+                    x_all = ho.vcycle(b); r2 += 1
+                t_all = (time.perf_counter() - t0) / r2
+            finally:
+                orc.set_threads(1)
         # parity of this very sample against the GPU cycle (cheap, keeps the baseline honest)
         xg = h.vcycle(ctx.vec(b)).numpy()
         err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
         out = {"grid": Ns, "rows": n, "levels": h.nlev, "cycles": reps, "ms_per_cycle": t_cycle * 1e3, "gpu_vs_oracle_rel_err": err}
+        if t_all is not None:
+            out["all_cores"] = {"threads": nthr, "ms_per_cycle": t_all * 1e3, "same_bits_as_one_thread": bool(np.array_equal(x_all, x))}
         del h, A, ho
         return out, (As[0] if keep_fine else None)
     finally:
@@ -203,6 +299,13 @@ def cpu_baseline(mg, args):
                      f"{full['cycles']} cycles of {full['ms_per_cycle']:.1f} ms after one warm-up cycle"
                      + ("" if scale == 1.0 else f", scaled by the row ratio x{scale:.0f} to {args.grid}^3"),
            "sample_ms_per_cycle": full["ms_per_cycle"], "gpu_vs_oracle_rel_err_on_sample": full["gpu_vs_oracle_rel_err"]}
+    if full.get("all_cores"):
+        # the whole CYCLE (not only its SpMV) on every host core this job may use: the box gives a 1-GPU job 16 of the host's hardware threads
+        # (os.sched_getaffinity), which is the cap stated here; value stays the 1-thread figure (how the reference ships: no -fopenmp)
+        ac = full["all_cores"]
+        out["vcycle_all_cores"] = {"value": 1.0 / (ac["ms_per_cycle"] * 1e-3 * scale), "unit": "V-cycles/s", "cores": ac["threads"], "ms_per_cycle": ac["ms_per_cycle"],
+                                   "same_bits_as_one_thread": ac["same_bits_as_one_thread"],
+                                   "note": "oracle cycle with its row loops (SpMV, residual, Jacobi, prolongation add) on all CPUs of this job's affinity mask"}
     if Ns > 256 and not args.no_cpu_cross:
         try:       # cross-check of the row scaling the earlier rounds reported (256^3 x 8)
             cross, _ = _oracle_sample(mg, orc, args, 256, 3, 3.0)
@@ -278,6 +381,8 @@ def parse_args():
     ap.add_argument("--no-cpu-cross", action="store_true", help="skip the 256^3 cross-check sample of the CPU baseline")
     ap.add_argument("--optin", action="store_true", help="also run the opt-in value-pattern leg (valcode=1; builds a second hierarchy; never the headline)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-convdiff", action="store_true", help="skip the 256^3 convection-diffusion leg (untimed solve comparison)")
+    ap.add_argument("--convdiff-grid", type=int, default=256)
     ap.add_argument("--kernel-reps", type=int, default=20)
     return ap.parse_args()
 
@@ -445,7 +550,7 @@ def main():
     # bytes the kernel streams by construction (8 B per entry + 17 B per row: x, y, pattern id; rowptr once per wave; tables), else the CSR byte count (plain CSR kernel)
     phys_bytes = traffic or streamed or spmv_bytes(n, nnz)
     phys_basis = (f"PMC traffic (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of {traffic_src} / this run's ms_per_launch" if traffic else
-                  ("bytes the kernel streams by construction / this run's ms_per_launch (no committed PMC summary for this grid)" if streamed else
+                  ("bytes the kernel streams by construction / this run's ms_per_launch (no committed PMC summary of THIS kernel source for this grid)" if streamed else
                    "CSR bytes / this run's ms_per_launch (plain CSR kernel)"))
     summ = pmc_summary(N)
     cyc = (summ[0].get("vcycle") if summ else None) or {}
@@ -466,6 +571,7 @@ def main():
         # effective rate and can exceed the peak.
         "roofline": {"bound": "hbm", "achieved": gbps(phys_bytes, ms_spmv), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps(phys_bytes, ms_spmv) / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "basis": phys_basis,
+                     "traffic_code_commit": (summ[0].get("code_commit") if summ else None), "kernel_source_sha": kernel_source_sha(),
                      "kernel": "csr_rowblock_coded_kernel<SPMV> (fine level; CSR SpMV with pattern-coded column index)",
                      "ms_per_launch": ms_spmv,
                      "effective_csr_bytes_per_launch": spmv_bytes(n, nnz), "effective_csr_gbps": spmv_gbps, "effective_csr_frac": spmv_gbps / HBM_PEAK_GBPS,
@@ -477,8 +583,8 @@ def main():
                      "csr_kernel": {"ms": ms_spmv_csr, "gbps": gbps(spmv_bytes(n, nnz), ms_spmv_csr), "frac": gbps(spmv_bytes(n, nnz), ms_spmv_csr) / HBM_PEAK_GBPS},
                      "other_kernels": {"residual": {"ms": ms_res, "effective_csr_gbps": gbps(residual_bytes(n, nnz), ms_res)},
                                        "jacobi": {"ms": ms_jac, "effective_csr_gbps": gbps(jacobi_bytes(n, nnz), ms_jac)}},
-                     # the cycle: PMC bytes of every dispatch of one cycle in the same profile set, over this run's ms_per_step (<= peak by
-                     # construction); the §8d byte count of the cycle's operations beside it as an effective figure
+                     # the cycle: PMC bytes of every dispatch of one cycle in the same profile set (same kernel source, see pmc_summary), over
+                     # this run's ms_per_step; the §8d byte count of the cycle's operations beside it as an effective figure
                      "vcycle_hbm_gb": cyc_bytes / 1e9 if cyc_bytes else None,
                      "vcycle_hbm_gbps": cyc_bytes / (ms_step * 1e-3) / 1e9 if cyc_bytes else None,
                      "vcycle_hbm_frac": cyc_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS if cyc_bytes else None,
@@ -490,8 +596,9 @@ def main():
                         "tuned_omega08_overcorrection16": {"status": stt, "iterations": itt, "true_residual": truet, "seconds": t_solve_t,
                                                             "note": "same V(1,1) cycle with omega = 0.8 and x += 1.6·P e_c (knobs the reference does not have)"},
                         "fgcr10_kcycle4_energy": {"ms_per_kcycle": ms_kcycle, "runs": kruns,
-                                                  "note": "FGCR(10) + K-cycle on levels 1-4 with energy (flexible-CG) coefficients, option kcycle_energy; "
-                                                          "derived from the paper, no reference executable (parity unpinned)"}},
+                                                  "spd_only": True,
+                                                  "note": "FGCR(10) + K-cycle on levels 1-4 with energy (flexible-CG) coefficients, option kcycle_energy: SYMMETRIC POSITIVE DEFINITE operators only "
+                                                          "(the nonsymmetric leg below uses the paper's GCR form); derived from the paper, no reference executable (parity unpinned)"}},
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
@@ -505,6 +612,18 @@ def main():
         out["bundled_matrices"] = bundled_cases(mg, args)
     except Exception as e:  # noqa: BLE001
         log("bundled cases failed:", repr(e))
+    if not args.no_convdiff:
+        try:
+            cd = convdiff_leg(mg, args, args.convdiff_grid)
+            out["solve_check"][f"convdiff_{args.convdiff_grid}"] = cd
+            out["solve_check"][f"convdiff_{args.convdiff_grid}"]["poisson_reference_us_per_million_rows"] = {"spmv": ms_spmv * 1e3 / (n / 1e6), "vcycle": ms_step * 1e3 / (n / 1e6)}
+            log(f"convection-diffusion {args.convdiff_grid}^3: SpMV {cd['spmv_us_per_million_rows']:.1f} us/Mrow (Poisson {ms_spmv * 1e3 / (n / 1e6):.1f}), cycle {cd['vcycle_us_per_million_rows']:.1f} "
+                f"(Poisson {ms_step * 1e3 / (n / 1e6):.1f}); " + "; ".join(
+                    f"seed {r['rhs_seed']}: BiCGSTAB+V {r['bicgstab_vcycle']['iterations']} it / {r['bicgstab_vcycle']['seconds']:.2f}s, FGCR+K {r['fgcr10_kcycle_gcr']['iterations']} it / "
+                    f"{r['fgcr10_kcycle_gcr']['seconds']:.2f}s" for r in cd["runs"]))
+        except Exception as e:  # noqa: BLE001
+            log("convection-diffusion leg failed:", repr(e))
+            out["solve_check"][f"convdiff_{args.convdiff_grid}"] = {"error": repr(e)}
     if not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(mg, args)

@@ -352,6 +352,10 @@ int mgs_hier_set_native_recv_segments(mgs_hier *h, int level, const int *nseg_pe
 int mgs_comm_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void *handle_out, mgs_comm **out);
 int mgs_comm_p2p_connect(mgs_comm *c, const void *handles);
 int mgs_comm_p2p_info(const mgs_comm *c, long long out[6]);
+/* COLLECTIVE self-test of a connected peer-to-peer communicator: `rounds` exchanges with every peer (sizes from the window slot down to a few
+ * doubles, both slots reused many times), every value a function of (round, sender, receiver, position) and verified on the device.
+ * *mismatches = wrong values this rank saw (0 = clean).  The launcher runs it before it trusts the transport on hardware it has not seen. */
+int mgs_comm_p2p_selftest(mgs_comm *c, int rounds, long long *mismatches);
 /* raw operations of a communicator (either transport) on the context's stream — transport tests and microbenchmarks; the cycle uses
  * them internally.  exchange: one group of sends (send_dev[q] != NULL) and receives (recv_dev[q] != NULL) of count[q] doubles with
  * rank peer[q]; the ops addressed to one peer are matched with that peer's ops in posting order.  allgather: count doubles per rank,

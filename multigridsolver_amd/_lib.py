@@ -45,6 +45,7 @@ PROTOTYPES = {
     "mgs_comm_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mgs_comm_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgs_comm_p2p_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgs_comm_p2p_selftest": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "mgs_comm_exchange_raw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgs_comm_allgather_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mgs_comm_allreduce_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

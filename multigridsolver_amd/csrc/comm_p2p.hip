@@ -46,6 +46,8 @@ struct P2PArgs {
   unsigned *arrive, *err;
   unsigned long long slot_doubles, timeout_ticks;
   int nseg, npeer, rank;
+  int tune;     // bits 0-1 release side (0 system fence, 1 agent fence, 2 wait for the stores' acknowledgement only), bit 2: no acquire fence.
+                // Uncached windows run 6, cached ones 0 (see mgs_p2p_create); MGS_P2P_TUNE overrides for experiments
 };
 
 // grid-stride copy with four 16-byte (or 8-byte) loads per lane in flight: the window is uncached memory, every load pays the full trip
@@ -97,12 +99,15 @@ __global__ __launch_bounds__(P2P_TB) void p2p_exchange_kernel(const P2PArgs a) {
     if (sg.kind == 1) continue;
     copy_range(sg.src, sg.dst + (sg.kind == 0 ? (s_seq[sg.peer] & 1ull) * a.slot_doubles : 0ull), sg.n);
   }
-  __threadfence_system();                       // every thread: its stores are performed system-wide before the workgroup arrives
+  // every thread: its stores are performed system-wide before the workgroup arrives
+  if ((a.tune & 3) == 0) __threadfence_system();
+  else if ((a.tune & 3) == 1) __threadfence();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) s_last = gridDim.x == 1 || atomicAdd(a.arrive, 1u) == gridDim.x - 1;      // (a single workgroup has nobody to wait for)
   __syncthreads();
   if (s_last) {                                 // everybody's ranges are out (and every workgroup has read the sequence numbers): publish
-    __threadfence_system();
+    if ((a.tune & 3) == 0) __threadfence_system(); else if ((a.tune & 3) == 1) __threadfence();
     if (tid < a.npeer) {
       __hip_atomic_store(a.flag_out[tid], s_seq[tid] + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       *a.seq[tid] = s_seq[tid] + 1ull;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(P2P_TB) void p2p_exchange_kernel(const P2PArgs a) {
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every wave: nothing of the window is served from a line fetched before the flag
+  if (!(a.tune & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every wave: nothing of the window is served from a line fetched before the flag
   if (s_bad) return;
   // ---- phase 3: window → destination
   for (int q = 0; q < a.nseg; ++q) {
@@ -138,7 +143,7 @@ struct P2PRedArgs {
   unsigned *err;
   double *buf;
   unsigned long long slot_doubles, timeout_ticks;
-  int npeer, rank, cnt;
+  int npeer, rank, cnt, tune;
 };
 __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PRedArgs a) {
   __shared__ unsigned long long s_seq[P2P_MAXPEER];
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PRedArgs a) {
   __syncthreads();
   const double mine = tid < a.cnt ? a.buf[tid] : 0.0;
   if (tid < a.cnt) for (int p = 0; p < a.npeer; ++p) a.peer_area[p][(s_seq[p] & 1ull) * a.slot_doubles + tid] = mine;
-  __threadfence_system();
+  if ((a.tune & 3) == 0) __threadfence_system(); else if ((a.tune & 3) == 1) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < a.npeer) {
     __hip_atomic_store(a.flag_out[tid], s_seq[tid] + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PRedArgs a) {
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (!(a.tune & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   if (s_bad || tid >= a.cnt) return;
   double s = 0.0;
   int p = 0;
@@ -184,6 +189,7 @@ struct mgs_p2p {
   unsigned *arrive = nullptr, *err = nullptr;
   unsigned long long timeout_ticks = 0;
   unsigned long long launches = 0;
+  int tune = 0; size_t block_doubles = 512;
   bool connected = false;
   unsigned long long *flag_of(char *w, int writer) const { return reinterpret_cast<unsigned long long *>(w + (size_t)writer * P2P_FLAG_STRIDE); }
   double *area_of(char *w, int writer) const { return reinterpret_cast<double *>(w + P2P_FLAG_BYTES + (size_t)writer * 2 * slot_doubles * sizeof(double)); }
@@ -225,6 +231,14 @@ int mgs_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void 
   const char *e = getenv("MGS_P2P_TIMEOUT_S");
   const double secs = e && atof(e) > 0.0 ? atof(e) : 20.0;
   c->timeout_ticks = (unsigned long long)(secs * 100e6);       // wall_clock64(): constant 100 MHz
+  // Uncached window (the default): its stores bypass every cache, so "performed" is the store's own acknowledgement (s_waitcnt vmcnt(0)) and its
+  // loads can never be served from a stale line — no L2 write-back / invalidate on either side.  Measured (tools/microbench/p2p_probe.cpp,
+  // profiles/r04_p2p_probe.md): 4.4 / 5.8 / 6.4 / 9.5 µs per exchange of 8 B / 32 KiB / 256 KiB / 2 MiB per neighbour against 5.9 / 7.8 / 17 / 30 µs
+  // with system-scope fences; the same shortcut on a cached window gives WRONG data between two processes (probe, "coarse"/"fine" rows),
+  // so cached windows keep the fences.
+  c->tune = c->mem_kind == 1 ? 6 : 0;
+  if (const char *t = getenv("MGS_P2P_TUNE")) c->tune = atoi(t);
+  if (const char *t = getenv("MGS_P2P_BLOCK_DOUBLES")) c->block_doubles = (size_t)std::max(atoi(t), 64);
   c->peer_win.assign((size_t)world, nullptr); c->opened.assign((size_t)world, false);
   c->peer_win[(size_t)rank] = c->win;
   c->connected = world == 1;
@@ -269,8 +283,22 @@ int mgs_p2p_info(const mgs_p2p *c, long long out[6]) {
 
 // workgroups of one exchange: one 16-byte load per lane up to 1 MiB per phase, four beyond (copy_range keeps four in flight); a message
 // of a few hundred doubles is one workgroup and skips the arrival counter
-static int grid_for(size_t doubles) {
-  const size_t per_block = (size_t)P2P_TB * 2;
+// ---- self-test: `rounds` exchanges with every peer, every value a function of (round, sender, receiver, position), verified ON THE DEVICE
+__global__ void p2p_fill_kernel(double *buf, unsigned n, int round, int from, int world) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x, tot = n * (unsigned)world;
+  if (i < tot) { const int to = (int)(i / n); buf[i] = (double)round * 1048576.0 + (double)from * 65536.0 + (double)to * 4096.0 + (double)(i % n) * 0.5; }
+}
+__global__ void p2p_check_kernel(const double *buf, unsigned n, int round, int me, int world, unsigned *bad) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x, tot = n * (unsigned)world;
+  if (i < tot) {
+    const int from = (int)(i / n);
+    if (from == me) return;
+    const double want = (double)round * 1048576.0 + (double)from * 65536.0 + (double)me * 4096.0 + (double)(i % n) * 0.5;
+    if (buf[i] != want) atomicAdd(bad, 1u);
+  }
+}
+
+static int grid_for(size_t doubles, size_t per_block = (size_t)P2P_TB * 2) {
   const size_t nb = (doubles + per_block - 1) / per_block;
   return (int)std::min<size_t>(std::max<size_t>(nb, 1), 256);
 }
@@ -309,11 +337,39 @@ int mgs_p2p_exchange_ops(mgs_p2p *c, hipStream_t s, const mgs_xfer_op *ops, int 
   }
   if (!a.npeer) return MGS_OK;
   most = std::max(pushed, unpacked);
-  a.arrive = c->arrive; a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks;
-  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(grid_for(most)), dim3(P2P_TB), 0, s, a);
+  a.arrive = c->arrive; a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks; a.tune = c->tune;
+  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(grid_for(most, c->block_doubles)), dim3(P2P_TB), 0, s, a);
   MGS_HIP(ctx, hipGetLastError());
   ++c->launches;
   return MGS_OK;
+}
+
+// COLLECTIVE: every rank sends every peer n values per round and checks what it received, rounds of growing size; *mismatches = wrong values seen here
+int mgs_p2p_selftest(mgs_p2p *c, hipStream_t s, int rounds, long long *mismatches) {
+  mgs_ctx *ctx = c->ctx;
+  MGS_CHECK(ctx, c->connected && mismatches && rounds >= 1, MGS_ERR_INVALID, "mgs_comm_p2p_selftest: bad arguments / not connected");
+  *mismatches = 0;
+  if (c->world == 1) return MGS_OK;
+  const size_t nmax = std::min<size_t>(c->slot_doubles, (size_t)1 << 16);
+  double *src = nullptr, *dst = nullptr; unsigned *bad = nullptr;
+  MGS_TRY(mgs_dev_alloc(ctx, &src, nmax * (size_t)c->world)); MGS_TRY(mgs_dev_alloc(ctx, &dst, nmax * (size_t)c->world)); MGS_TRY(mgs_dev_alloc(ctx, &bad, 1));
+  MGS_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(unsigned), s));
+  int rc = MGS_OK;
+  for (int r = 0; r < rounds && rc == MGS_OK; ++r) {
+    const size_t n = std::max<size_t>(1, (nmax >> (r % 12)));            // 64 Ki doubles down to a handful, again and again
+    const unsigned tot = (unsigned)(n * (size_t)c->world);
+    hipLaunchKernelGGL(p2p_fill_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, src, (unsigned)n, r, c->rank, c->world);
+    std::vector<mgs_xfer_op> ops;
+    for (int p = 0; p < c->world; ++p) if (p != c->rank) { ops.push_back({src + (size_t)p * n, nullptr, n, p}); ops.push_back({nullptr, dst + (size_t)p * n, n, p}); }
+    rc = mgs_p2p_exchange_ops(c, s, ops.data(), (int)ops.size());
+    hipLaunchKernelGGL(p2p_check_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, dst, (unsigned)n, r, c->rank, c->world, bad);
+  }
+  unsigned hb = 0;
+  if (rc == MGS_OK && (hipMemcpyAsync(&hb, bad, sizeof hb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = mgs_fail(ctx, MGS_ERR_HIP, "p2p self-test: reading the result failed");
+  else (void)hipStreamSynchronize(s);
+  mgs_hip_free(src); mgs_hip_free(dst); mgs_hip_free(bad);
+  *mismatches = (long long)hb;
+  return rc;
 }
 
 int mgs_p2p_allgather(mgs_p2p *c, hipStream_t s, const double *send, double *recv, size_t count) {
@@ -331,8 +387,8 @@ int mgs_p2p_allgather(mgs_p2p *c, hipStream_t s, const double *send, double *rec
     a.seg[a.nseg++] = P2PSeg{c->area_of(c->win, p), recv + (size_t)p * count, (unsigned)count, (short)k, 1};
   }
   if (send != recv + (size_t)c->rank * count) a.seg[a.nseg++] = P2PSeg{send, recv + (size_t)c->rank * count, (unsigned)count, 0, 2};
-  a.arrive = c->arrive; a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks;
-  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(grid_for(count * (size_t)(c->world - 1))), dim3(P2P_TB), 0, s, a);
+  a.arrive = c->arrive; a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks; a.tune = c->tune;
+  hipLaunchKernelGGL(p2p_exchange_kernel, dim3(grid_for(count * (size_t)(c->world - 1), c->block_doubles)), dim3(P2P_TB), 0, s, a);
   MGS_HIP(ctx, hipGetLastError());
   ++c->launches;
   return MGS_OK;
@@ -351,7 +407,7 @@ int mgs_p2p_allreduce_sum(mgs_p2p *c, hipStream_t s, double *buf, size_t count) 
     a.flag_out[k] = c->flag_of(c->peer_win[(size_t)p], c->rank); a.flag_in[k] = c->flag_of(c->win, p); a.seq[k] = c->seq + p;
     a.peer_rank[k] = (short)p;
   }
-  a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks;
+  a.err = c->err; a.slot_doubles = c->slot_doubles; a.timeout_ticks = c->timeout_ticks; a.tune = c->tune;
   hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(64), 0, s, a);
   MGS_HIP(ctx, hipGetLastError());
   ++c->launches;

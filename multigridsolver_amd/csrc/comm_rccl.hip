@@ -107,6 +107,10 @@ int mgs_comm_p2p_connect(mgs_comm *c, const void *handles) {
   MGS_CHECK(c->ctx, c->p2p, MGS_ERR_STATE, "mgs_comm_p2p_connect: not a peer-to-peer communicator");
   return mgs_p2p_connect(c->p2p, handles);
 }
+int mgs_comm_p2p_selftest(mgs_comm *c, int rounds, long long *mismatches) {
+  MGS_CHECK(c->ctx, c->p2p, MGS_ERR_STATE, "mgs_comm_p2p_selftest: not a peer-to-peer communicator");
+  return mgs_p2p_selftest(c->p2p, c->ctx->stream, rounds, mismatches);
+}
 int mgs_comm_p2p_info(const mgs_comm *c, long long out[6]) {
   MGS_CHECK(c->ctx, c->p2p && out, MGS_ERR_STATE, "mgs_comm_p2p_info: not a peer-to-peer communicator");
   return mgs_p2p_info(c->p2p, out);

@@ -437,18 +437,43 @@ __global__ __launch_bounds__(TB) void mdot_final_kernel(int nb, int K, const dou
 // (z·z, z·u) accumulated in the same pass (u = NULL: second sum stays 0) — the orthogonalisation update of the flexible Krylov
 // methods: the new direction against the window, its norm and its product with the residual, one read of every vector.
 struct MAxpyArgs { const double *w[MDOT_MAX]; double coef[MDOT_MAX]; };
+template <bool VEC>
 __global__ __launch_bounds__(TB) void maxpy_dot2_kernel(int64_t n, int K, const double *__restrict__ x, const MAxpyArgs W, double *__restrict__ z,
                                                         const double *__restrict__ u, const double *__restrict__ u2, double *__restrict__ part) {
   __shared__ double sh[2][TB / 64];
   double s0 = 0.0, s1 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * TB;
-  for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) {
-    double zi = x[i];
+  if (VEC) {              // 16 bytes per lane and stream (every operand 16-byte aligned; an odd last element goes to one lane below)
+    const int64_t n2 = n >> 1;
+    const vd2 *__restrict__ xv = reinterpret_cast<const vd2 *>(x);
+    vd2 *__restrict__ zv = reinterpret_cast<vd2 *>(z);
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n2; i += stride) {
+      vd2 zi = xv[i];
 #pragma unroll
-    for (int k = 0; k < MDOT_MAX; ++k) if (k < K) zi -= W.coef[k] * W.w[k][i];
-    z[i] = zi;
-    s0 += zi * (u2 ? u2[i] : zi);
-    if (u) s1 += zi * u[i];
+      for (int k = 0; k < MDOT_MAX; ++k)
+        if (k < K) { const vd2 wi = reinterpret_cast<const vd2 *>(W.w[k])[i]; zi.x -= W.coef[k] * wi.x; zi.y -= W.coef[k] * wi.y; }
+      zv[i] = zi;
+      if (part) {
+        if (u2) { const vd2 q = reinterpret_cast<const vd2 *>(u2)[i]; s0 += zi.x * q.x; s0 += zi.y * q.y; } else { s0 += zi.x * zi.x; s0 += zi.y * zi.y; }
+        if (u) { const vd2 q = reinterpret_cast<const vd2 *>(u)[i]; s1 += zi.x * q.x; s1 += zi.y * q.y; }
+      }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+      double zi = x[n - 1];
+      for (int k = 0; k < K; ++k) zi -= W.coef[k] * W.w[k][n - 1];
+      z[n - 1] = zi;
+      s0 += zi * (u2 ? u2[n - 1] : zi);
+      if (u) s1 += zi * u[n - 1];
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) {
+      double zi = x[i];
+#pragma unroll
+      for (int k = 0; k < MDOT_MAX; ++k) if (k < K) zi -= W.coef[k] * W.w[k][i];
+      z[i] = zi;
+      s0 += zi * (u2 ? u2[i] : zi);
+      if (u) s1 += zi * u[i];
+    }
   }
   if (!part) return;                               // plain multi-axpy
   for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
@@ -661,7 +686,7 @@ __global__ void poisson2d_kernel(int n, int *__restrict__ rowptr, int *__restric
 
 // ============================================================ host launchers
 // Grid of the 16-byte update kernels: ONE pair per lane, one-shot workgroups (the loop in the kernels then runs once).  Measured at
-// 512³ (tools/blas1_grid.py): axpby 0.695 ms with the capped persistent grid (n_cu × 8 workgroups, grid-stride, unroll 4), 0.541 ms
+// 512³ (tools/studies_r1_r3/blas1_grid.py): axpby 0.695 ms with the capped persistent grid (n_cu × 8 workgroups, grid-stride, unroll 4), 0.541 ms
 // one-shot (5.96 TB/s); 2 / 4 / 8 pairs per lane: 0.568 / 0.623 / 0.671 ms — on this part a stream wants many short-lived
 // workgroups, not a few resident ones (the row-block kernels are one-shot already; tools/microbench/rw_mix.hip shows the same).
 // Option blas1_pairs = k: k pairs per lane (0: the capped grid), for that A/B.
@@ -801,7 +826,7 @@ int k_concat_i32(mgs_ctx *ctx, const int *a, int na, const int *b, int nb, int *
 // context's mapped, coherent host buffer, then a ticket (system-scope release); the host polls the ticket.  Against hipMemcpyAsync + hipStreamSynchronize this removes
 // the blit/SDMA hop and the interrupt wake-up from every inner product of a Krylov loop: four per BiCGSTAB iteration — ≈ 60 of the
 // 135 µs of an iteration on the bundled operators, and on a freshly started box, where the first process' wake-ups take milliseconds,
-// 13 of 33 ms per iteration at 512³ (tools/solve_repeat.py).  Option post_results = 0 restores copy + synchronize; so does any
+// 13 of 33 ms per iteration at 512³ (tools/studies_r1_r3/solve_repeat.py).  Option post_results = 0 restores copy + synchronize; so does any
 // transport that sums over ranks in between (ncomm / all-reduce callback), and a wait that sees no ticket for 2 s.
 static Post begin_post(mgs_ctx *ctx) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -984,11 +1009,14 @@ int k_maxpy_dot2(mgs_ctx *ctx, int64_t n, int K, const double *x, const double *
   MGS_CHECK(ctx, K >= 0 && K <= MDOT_MAX, MGS_ERR_INVALID, "k_maxpy_dot2: %d terms (at most %d)", K, MDOT_MAX);
   MAxpyArgs W;
   for (int k = 0; k < MDOT_MAX; ++k) { W.w[k] = k < K ? w[k] : x; W.coef[k] = k < K ? coef[k] : 0.0; }
-  int64_t nbl = (n + (int64_t)TB * 2 - 1) / ((int64_t)TB * 2);
+  bool vec = n >= 2 && al16(x) && al16(z) && (!u || al16(u)) && (!u2 || al16(u2));
+  for (int k = 0; k < K; ++k) vec = vec && al16(w[k]);
+  int64_t nbl = (n + (int64_t)TB * 4 - 1) / ((int64_t)TB * 4);       // two 16-byte (or four 8-byte) elements per lane
   const int nb = (int)std::min<int64_t>(std::max<int64_t>(nbl, 1), 1 << 20);
   double *part = nullptr;
   if (out_host2) { part = ctx->red_dev; if (nb > DOT_BLOCKS / 2) { MGS_TRY(mgs_ensure_dot_part(ctx, 2 * (int64_t)nb)); part = ctx->dot_part; } }
-  hipLaunchKernelGGL(maxpy_dot2_kernel, dim3(nb), dim3(TB), 0, ctx->stream, n, K, x, W, z, u, u2, part);
+  if (vec) hipLaunchKernelGGL(maxpy_dot2_kernel<true>, dim3(nb), dim3(TB), 0, ctx->stream, n, K, x, W, z, u, u2, part);
+  else hipLaunchKernelGGL(maxpy_dot2_kernel<false>, dim3(nb), dim3(TB), 0, ctx->stream, n, K, x, W, z, u, u2, part);
   MGS_HIP(ctx, hipGetLastError());
   return out_host2 ? k_dot2_finish(ctx, nb, part, out_host2) : MGS_OK;
 }

@@ -17,7 +17,7 @@
 // fit the LDS budget (long rows) fall back, per block, to a sub-wavefront-per-row reduction with
 // shuffles.  The workgroup→row-block map is XCD-contiguous (each of the 8 XCDs sweeps one eighth
 // of the rows so re-read x planes stay in that XCD's 4 MiB L2), optionally strip-major.
-// The earlier "products in LDS" variants are kept for A/B runs (tools/ab_spmv.py).
+// The earlier "products in LDS" variants are kept for A/B runs (tools/studies_r1_r3/ab_spmv.py).
 // Default path for operators whose rows repeat their shape (stencils, their Galerkin levels): the same row-block
 // kernel with a PATTERN-CODED column index (csr_rowblock_coded_kernel, mgs_csr_optimize) — 8 B per entry streamed
 // instead of 12, same products in the same order; irregular row blocks keep their index slice.
@@ -914,9 +914,15 @@ __global__ __launch_bounds__(RB) void csr_group_pre_kernel(
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
     double *__restrict__ rc_out, const int *__restrict__ gdesc, const unsigned long long *__restrict__ acode,
-    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts /*bit 0: streaming store of t; bit 1: slice staged by LDS-DMA, no loop; bit 2: option rowptr_scan*/) {
+    const unsigned *__restrict__ wmask, int capv, int capi, BlockMap bm, const double *__restrict__ hv, int split, int nts /*bit 0: streaming store of t; bit 1: slice staged by LDS-DMA, no loop; bit 2: option rowptr_scan*/,
+    const int *__restrict__ gorder, int gper) {
   extern __shared__ double lds_raw[];
-  const int g = map_block(bm, blockIdx.x);
+  int g;
+  if (gorder) {        // option group_order: workgroup (xcd, idx) → group, in the order of the one-block kernels' plane sweep
+    const int idx = blockIdx.x >> 3;
+    if (idx >= gper) return;
+    g = gorder[(blockIdx.x & 7) * gper + idx];
+  } else g = map_block(bm, blockIdx.x);
   if (g < 0) return;
   const int tid = threadIdx.x;
   double *__restrict__ vals = lds_raw;                                    // capv + 2 doubles
@@ -1468,7 +1474,7 @@ static dim3 plan_group_map(const mgs_csr *A, const mgs_groups *G, BlockMap &bm) 
 void mgs_free_groups(mgs_groups *g) {
   if (!g) return;
   if (g->gblk) mgs_hip_free(g->gblk); if (g->afirst) mgs_hip_free(g->afirst); if (g->acode) mgs_hip_free(g->acode); if (g->gdesc) mgs_hip_free(g->gdesc);
-  if (g->wmask) mgs_hip_free(g->wmask); if (g->stray) mgs_hip_free(g->stray);
+  if (g->wmask) mgs_hip_free(g->wmask); if (g->stray) mgs_hip_free(g->stray); if (g->gorder) mgs_hip_free(g->gorder);
   delete g;
 }
 // Pairs the row blocks of A along its aggregates (see csr_group_pre_kernel).  *out stays NULL when the level does not
@@ -1579,6 +1585,24 @@ int mgs_build_groups(mgs_ctx *ctx, const mgs_csr *A, const mgs_xfer *T, mgs_grou
           if (b >= 0) maxb = std::max(maxb, q + 1);
         }
       G->max_blocks = maxb;
+      // option group_order: the groups in the order in which the one-block kernels sweep their FIRST blocks — XCD-contiguous ranges of row
+      // blocks, inside a range strip-major: a strip of S row blocks followed through every plane (period Db blocks) of the range
+      const int Db = (A->far_band + RB - 1) / RB, chunkB = (nblocks + 7) / 8, S = ctx->opt_group_order;
+      if (rc == MGS_OK && S > 0 && Db >= 512 && chunkB >= 2 * Db) {
+        std::vector<std::vector<std::pair<long long, int>>> per(8);
+        for (int g = 0; g < ng; ++g) {
+          const int fb = hg[(size_t)g * GRP_BLOCKS], xcd = std::min(fb / chunkB, 7), lb = fb - xcd * chunkB;
+          const long long p = lb / Db, off = lb % Db, st = off / S, t = off % S;
+          per[(size_t)xcd].push_back({(st * (long long)(chunkB / Db + 2) + p) * S + t, g});
+        }
+        size_t mx = 0;
+        for (auto &v : per) { std::sort(v.begin(), v.end()); mx = std::max(mx, v.size()); }
+        std::vector<int> ho(8 * mx, -1);
+        for (int x = 0; x < 8; ++x) for (size_t q = 0; q < per[(size_t)x].size(); ++q) ho[(size_t)x * mx + q] = per[(size_t)x][q].second;
+        rc = mgs_dev_alloc(ctx, &G->gorder, ho.size());
+        if (rc == MGS_OK && hipMemcpy(G->gorder, ho.data(), sizeof(int) * ho.size(), hipMemcpyHostToDevice) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping: order table upload failed");
+        G->gorder_per_xcd = (int)mx;
+      }
       if (rc == MGS_OK) rc = mgs_dev_alloc(ctx, &G->gdesc, hd.size());
       if (rc == MGS_OK && hipMemcpy(G->gdesc, hd.data(), sizeof(int) * hd.size(), hipMemcpyHostToDevice) != hipSuccess) rc = mgs_fail(ctx, MGS_ERR_HIP, "row-block grouping: descriptor upload failed");
       usable = rc == MGS_OK;
@@ -1603,17 +1627,20 @@ int mgs_launch_group_pre(const mgs_csr *A, const mgs_groups *G, const mgs_xfer *
   const int capi = lean ? std::max(c->tab_cap, 64) : std::max(c ? c->tab_cap : 0, capv + 2);
   const size_t lds = (size_t)(capv + 2) * 8 + (size_t)((capi + 1) / 2) * 8 + (size_t)G->max_blocks * RB * 8 + 16 + (size_t)ctx->opt_lds_pad;
   BlockMap bm;
-  const dim3 grid = plan_group_map(A, G, bm);
+  dim3 grid = plan_group_map(A, G, bm);
   const double mean_len = A->rows ? (double)A->nnz / A->rows : 1.0;
   const int u = mean_len <= 4.5 ? 4 : (mean_len <= 7.5 && A->max_row_len <= 14 ? 7 : 8);
   const bool pairs = G->max_blocks <= 2 && ctx->opt_group_concurrent;     // 512 threads, both blocks of a pair at once
+  const bool ordered = !pairs && G->gorder && ctx->opt_group_order > 0 && ctx->opt_xcd_remap;
+  if (ordered) grid = dim3(8 * G->gorder_per_xcd);
   const size_t lds2 = (size_t)2 * ((size_t)(capv + 2) * 8 + (size_t)((capi + 1) / 2) * 8) + (size_t)2 * RB * 8 + 16 + (size_t)ctx->opt_lds_pad;
 #define G2_(UU, H) hipLaunchKernelGGL((csr_group2_pre_kernel<UU, H>), grid, dim3(2 * RB), lds2, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                       c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
                                       G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff)
 #define G_(UU, H) hipLaunchKernelGGL((csr_group_pre_kernel<UU, H>), grid, dim3(RB), lds, ctx->stream, A->rows, A->rowptr, A->col, A->val, \
                                      c ? c->pid : nullptr, c ? c->tptr : nullptr, c ? c->tab : nullptr, x, b, t_out, r_out, rc_out, G->gdesc, \
-                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, ((ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0) | (ctx->opt_rowptr_scan ? 4 : 0))
+                                     G->acode, G->wmask, capv, capi, bm, hv, hv ? split : 0x7fffffff, ((ctx->opt_nt_store > 0 && A->rows >= ctx->opt_nt_store) ? 1 : 0) | (ctx->opt_stage_unroll ? 2 : 0) | (ctx->opt_rowptr_scan ? 4 : 0), \
+                                     ordered ? G->gorder : nullptr, G->gorder_per_xcd)
 #define GU_(UU) do { if (pairs) { if (hv) G2_(UU, true); else G2_(UU, false); } else { if (hv) G_(UU, true); else G_(UU, false); } } while (0)
   if (u == 4) GU_(4); else if (u == 7) GU_(7); else GU_(8);
 #undef GU_

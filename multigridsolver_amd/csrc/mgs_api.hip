@@ -254,6 +254,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "fuse_dots") ctx->opt_fuse_dots = value;
   else if (k == "merge_ap") ctx->opt_merge_ap = value;
   else if (k == "group_strip") ctx->opt_group_strip = value;
+  else if (k == "group_order") ctx->opt_group_order = value;
   else if (k == "group_stray_pct") ctx->opt_group_stray_pct = value;
   else if (k == "group_blocks") ctx->opt_group_blocks = value;
   else if (k == "group_min_link") ctx->opt_group_min_link = value;

@@ -43,6 +43,8 @@ struct mgs_ctx {
   int opt_lds_pad = 0;   // extra dynamic LDS bytes per workgroup (occupancy experiments only)
   int opt_strip = -1;  // strip-major sweep: -1 auto (32 row blocks), 0 off, >0 strip size in row blocks
   int opt_group_strip = 0;       // groups per strip of the grouped pre pass's strip-major sweep (0: from opt_strip)
+  int opt_group_order = 0;       // > 0: the grouped pre pass visits its groups in the order of the ONE-BLOCK kernels' strip-major plane sweep, strips of this many
+                                 // row blocks, through a table built with the groups (groups hold 1–4 blocks, so a period counted in groups drifts against the planes)
   int opt_merge_ap = 1;          // fused post pass on A·P (merged entries) instead of A with aggregate-mapped columns
   int opt_fuse_dots = 1;         // BiCGSTAB: r̃·v and (t·s, t·t) in the epilogue of the SpMV that produces v resp. t
   int opt_diag_from_values = 1;  // t-form post pass: ωD⁻¹ from the streamed diagonal entry (1 B per row of position) instead of the wd vector (8 B per row)
@@ -53,7 +55,7 @@ struct mgs_ctx {
                                  // 6.59 ms per cycle against 6.50 for the sequential sweep of the same pairs and 6.13 for 4-block groups — kept for A/B)
   int opt_group_min_link = 1;   // ... aggregates two row blocks must share to be grouped (8: keeps a few odd boundary aggregates from pulling blocks of
                                 // another plane into the group — 8 % less HBM traffic for that kernel, yet 2 % slower: fewer, fatter workgroups win)
-  int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/ab_group2.py): 4-block groups 6.21 ms per cycle,
+  int opt_group_blocks = 4;    // ... row blocks per group (1..4); same-process A/B at 512³ (tools/studies_r1_r3/ab_group2.py): 4-block groups 6.21 ms per cycle,
                                // pairs 6.34 ms, separate kernels 6.64 ms
   int opt_group_stray_pct = 6; // ... unless more than this share of a level's aggregates leaves its row-block group
   int opt_post_results = 1;   // inner products reach the host through a mapped buffer + ticket the host polls (no copy engine, no interrupt)
@@ -151,6 +153,7 @@ int mgs_p2p_create(mgs_ctx *ctx, int world, int rank, size_t slot_doubles, void 
 int mgs_p2p_connect(mgs_p2p *c, const void *handles);
 void mgs_p2p_destroy(mgs_p2p *c);
 int mgs_p2p_info(const mgs_p2p *c, long long out[6]);
+int mgs_p2p_selftest(mgs_p2p *c, hipStream_t s, int rounds, long long *mismatches);
 int mgs_p2p_exchange_ops(mgs_p2p *c, hipStream_t s, const mgs_xfer_op *ops, int nops);
 int mgs_p2p_allgather(mgs_p2p *c, hipStream_t s, const double *send, double *recv, size_t count);
 int mgs_p2p_allreduce_sum(mgs_p2p *c, hipStream_t s, double *buf, size_t count);
@@ -198,6 +201,7 @@ struct mgs_groups {
                                         // residual buffer; 0 = stray
   unsigned *wmask = nullptr;            // (n+31)/32 bit mask: rows that also store r (members of stray aggregates)
   int *stray = nullptr;                 // stray aggregate ids
+  int *gorder = nullptr; int gorder_per_xcd = 0;   // option group_order: group of workgroup (xcd, idx) at [xcd·per_xcd + idx], −1 = none
 };
 struct mgs_level {
   const mgs_csr *A = nullptr;

@@ -341,7 +341,7 @@ class ShardedHierarchy:
     # split-phase form: the library runs the interior row blocks between begin and end
     def _exchange_begin(self, level, x_ptr):
         # asynchronous work objects cost ~25 us more host time than the blocking form (measured,
-        # tools/exchange_overhead.py): worth it only where the interior kernel is long enough to hide it
+        # tools/studies_r1_r3/exchange_overhead.py): worth it only where the interior kernel is long enough to hide it
         big = self.plans[level].n_loc >= self.overlap_min_rows
         self._pending[level] = self._exchange(level, x_ptr, async_op=big)
 
@@ -521,6 +521,18 @@ class ShardedHierarchy:
                 ok = False; err = e
             if not agree(ok):
                 return fail("mapping the peers' windows", locals().get("err"))
+            # collective self-test before anything relies on the windows: 240 pattern exchanges with every peer, verified on the device
+            # (sizes 512 KiB ... 8 B, both window slots reused throughout) — this is the first time the transport sees THIS machine's links
+            try:
+                bad = C.c_longlong(-1)
+                check(lib().mgs_comm_p2p_selftest(c, int(os.environ.get("MGS_P2P_SELFTEST_ROUNDS", "240")), C.byref(bad)), ctx.h)
+                ok = bad.value == 0
+                if not ok:
+                    err = RuntimeError(f"{bad.value} wrong values received")
+            except Exception as e:  # noqa: BLE001
+                ok = False; err = e
+            if not agree(ok):
+                return fail("self-test of the windows", locals().get("err"))
         try:      # local: plans and tail into the C++ cycle
             ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.c_void_p)  # noqa: E731
             for l, plan in enumerate(self.plans):

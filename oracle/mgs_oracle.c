@@ -104,10 +104,26 @@ int orc_mtx_write(const char *path, const orc_csr *m) {
 
 /* ------------------------------------------------------------ primitives */
 
+/* Row loops may run on several host threads (bench.py's "all host cores" CPU baseline; default ONE thread, which is what every test
+ * uses): rows are independent and each row's sum keeps its sequential order, so the bits do not depend on the thread count.  Inner
+ * products stay sequential. */
+#ifdef _OPENMP
+#include <omp.h>
+static int g_orc_threads = 1;
+void orc_set_threads(int n) { g_orc_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_orc_threads; }
+#define ORC_PAR _Pragma("omp parallel for schedule(static) num_threads(g_orc_threads)")
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_get_threads(void) { return 1; }
+#define ORC_PAR
+#endif
+
 /* lib/Eigen/src/SparseCore/SparseDenseProduct.h:64-70 (processRow): tmp = 0;
  * for it in row: tmp += it.value() * rhs(it.index()); res(i) += alpha*tmp
  * with alpha = 1 on a zeroed res. */
 void orc_spmv(const orc_csr *A, const double *x, double *y) {
+  ORC_PAR
   for (int i = 0; i < A->rows; i++) {
     double tmp = 0.0;
     for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) tmp += A->val[k] * x[A->col[k]];
@@ -206,6 +222,7 @@ void orc_diag_inv(const orc_csr *A, double *dinv) {
 
 /* bicg.cpp:82: r = b − A*x */
 void orc_residual(const orc_csr *A, const double *x, const double *b, double *r) {
+  ORC_PAR
   for (int i = 0; i < A->rows; i++) {
     double tmp = 0.0;
     for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) tmp += A->val[k] * x[A->col[k]];
@@ -217,6 +234,7 @@ void orc_residual(const orc_csr *A, const double *x, const double *b, double *r)
  * Evaluation order fixed as  x_out = x_in + (ω·dinv_i)·(b_i − (Ax)_i). */
 void orc_jacobi(const orc_csr *A, const double *dinv, double omega,
                 const double *b, const double *x_in, double *x_out) {
+  ORC_PAR
   for (int i = 0; i < A->rows; i++) {
     double tmp = 0.0;
     for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) tmp += A->val[k] * x_in[A->col[k]];
@@ -440,7 +458,7 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
     for (int i = 0; i < n; i++) x[i] = tmp[i] + (h->omega * h->dinv[l][i]) * b[i];
     return;
   }
-  if (zero_guess) for (int i = 0; i < n; i++) x[i] = 0.0;
+  if (zero_guess) { ORC_PAR for (int i = 0; i < n; i++) x[i] = 0.0; }
   for (int s = 0; s < h->nu1; s++) {
     orc_jacobi(A, h->dinv[l], h->omega, b, x, tmp);
     memcpy(x, tmp, sizeof(double) * (size_t)n);
@@ -449,6 +467,7 @@ static void vcycle_rec(const orc_hier *h, int l, const double *b, double *x, int
   orc_spmv(&h->Pt[l], r, h->bc[l + 1]);
   coarse_solve_rec(h, l + 1, h->bc[l + 1], h->xc[l + 1]);
   orc_spmv(&h->P[l], h->xc[l + 1], tmp);
+  ORC_PAR
   for (int i = 0; i < n; i++) x[i] += tmp[i];
   for (int s = 0; s < h->nu2; s++) {
     orc_jacobi(A, h->dinv[l], h->omega, b, x, tmp);

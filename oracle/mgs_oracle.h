@@ -117,4 +117,8 @@ int orc_agmg(const orc_csr *A, double ktg, int npass, double tou,
 #ifdef __cplusplus
 }
 #endif
+/* host threads of the row loops (bench.py's all-cores CPU baseline; default 1 — bits do not depend on it) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
 #endif

@@ -65,8 +65,16 @@ def lib():
         L.orc_poisson2d.argtypes = [C.c_int, cp]
         L.orc_poisson3d.argtypes = [C.c_int, cp]
         L.orc_agmg.argtypes = [cp, C.c_double, C.c_int, C.c_double, C.c_int, cp]
+        L.orc_set_threads.argtypes = [C.c_int]; L.orc_set_threads.restype = None
+        L.orc_get_threads.argtypes = []; L.orc_get_threads.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """host threads of the oracle's row loops (default 1; the bits do not depend on it — rows are independent)"""
+    lib().orc_set_threads(int(n))
+    return lib().orc_get_threads()
 
 
 def _dp(a):

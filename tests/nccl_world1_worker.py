@@ -57,28 +57,38 @@ def main():
     A = ctx.poisson3d(N, lo, hi, local_cols=True)
     ids = np.concatenate([np.arange(n_loc - n2, n_loc), np.arange(0, n2)]).astype(np.int32)
     res = {}
-    for native in (True, False):
+    for native in ("rccl", "p2p", False):       # both native transports (real RCCL at world 1; the peer-to-peer windows) and the callbacks
+        if native:
+            os.environ["MGS_NATIVE_TRANSPORT"] = native
         shh = mgd.ShardedHierarchy(ctx, A, mgd.LevelPlan(n_loc, [ids], [ids]), 0.6, 1, 1, comm)
         shh.overlap_min_rows = 0; ctx.set_option("split_min_rows", 0)
-        shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=native)
-        assert shh.native == native and len(shh.plans) >= 3, (shh.native, len(shh.plans))
+        shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=bool(native))
+        assert shh.native == bool(native) and (not native or shh.native_transport == native) and len(shh.plans) >= 3, (shh.native, shh.native_transport, len(shh.plans))
         b = ctx.vec(n_loc).rand(seed=5); xx = ctx.vec(A.shape[1])
         shh.vcycle(b, xx)
         xs = ctx.vec(A.shape[1]).rand(seed=6); ys = ctx.vec(n_loc); shh.spmv(xs, ys)
         xsol = ctx.vec(A.shape[1]); st, it, tol = shh.bicgstab(xsol, b, 200, 1e-9)
         res[native] = (xx.numpy(n_loc), ys.numpy(), st, it, xsol.numpy(n_loc))
         shh.close(); del shh, b, xx, xs, ys, xsol
-    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
-    assert res[True][2] == 0 and res[True][2:4] == res[False][2:4] and np.array_equal(res[True][4], res[False][4]), (res[True][2:4], res[False][2:4])
-    # a rank that cannot resolve RCCL: every rank falls back to the callback path, the cycle still runs
+    for tr in ("rccl", "p2p"):
+        assert np.array_equal(res[tr][0], res[False][0]) and np.array_equal(res[tr][1], res[False][1]), tr
+        assert res[tr][2] == 0 and res[tr][2:4] == res[False][2:4] and np.array_equal(res[tr][4], res[False][4]), (tr, res[tr][2:4], res[False][2:4])
+    # a rank that cannot resolve RCCL: with the default order the peer-to-peer transport serves; restricted to RCCL every rank falls back
+    # to the callback path, and the cycle still runs
     os.environ["MGS_LIBRCCL"] = "/nonexistent/librccl.so"
+    os.environ["MGS_NATIVE_TRANSPORT"] = "p2p,rccl"
+    shh = mgd.ShardedHierarchy(ctx, A, mgd.LevelPlan(n_loc, [ids], [ids]), 0.6, 1, 1, comm)
+    shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=True)
+    assert shh.native is True and shh.native_transport == "p2p"
+    shh.close(); del shh
+    os.environ["MGS_NATIVE_TRANSPORT"] = "rccl"
     shh = mgd.ShardedHierarchy(ctx, A, mgd.LevelPlan(n_loc, [ids], [ids]), 0.6, 1, 1, comm)
     shh.build(10.0, 2, 8.0, tail_rows=3000, coarse_rows=100, native=True)
     assert shh.native is False
     b = ctx.vec(n_loc).rand(seed=5); xx = ctx.vec(A.shape[1]); shh.vcycle(b, xx)
     assert np.array_equal(xx.numpy(n_loc), res[False][0])
     shh.close(); del shh, b, xx
-    del os.environ["MGS_LIBRCCL"]
+    del os.environ["MGS_LIBRCCL"]; del os.environ["MGS_NATIVE_TRANSPORT"]
     print("NCCL_W1_OK")
     ctx.close()
     dist.destroy_process_group()

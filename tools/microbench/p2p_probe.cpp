@@ -58,10 +58,12 @@ int main(int argc, char **argv) {
   barrier(2);
   long long info[6];
   CK(mgs_comm_p2p_info(c, info));
-  if (R == 0) printf("world %d on one GPU; window %lld bytes, memory kind %lld (1 uncached, 2 fine-grained, 3 coarse)\n", W, info[1], info[0]);
+  if (R == 0) printf("world %d on one GPU; window %lld bytes, memory kind %lld (1 uncached, 2 fine-grained, 3 coarse); MGS_P2P_TUNE=%s MGS_P2P_BLOCK_DOUBLES=%s\n", W, info[1], info[0],
+                     getenv("MGS_P2P_TUNE") ? getenv("MGS_P2P_TUNE") : "-", getenv("MGS_P2P_BLOCK_DOUBLES") ? getenv("MGS_P2P_BLOCK_DOUBLES") : "-");
+  const bool brief = getenv("P2P_PROBE_BRIEF") != nullptr;
   const int lo = (R + W - 1) % W, hi = (R + 1) % W;
   int gen = 2;
-  for (size_t n : {(size_t)1, (size_t)4096, (size_t)262144}) {
+  for (size_t n : {(size_t)1, (size_t)4096, (size_t)32768, (size_t)262144}) {
     mgs_vec *src = nullptr, *dst = nullptr;
     CK(mgs_vec_create(ctx, (int64_t)n * 2, &src)); CK(mgs_vec_create(ctx, (int64_t)n * 2, &dst));
     std::vector<double> h(2 * n), g(2 * n);
@@ -143,10 +145,19 @@ int main(int argc, char **argv) {
     if (R == 0) printf("all-gather and all-reduce exact on every rank; all-reduce of 5 doubles %.2f us (eager)\n", 1e3 * ms / 200);
     mgs_vec_destroy(s); mgs_vec_destroy(all); mgs_vec_destroy(red);
   }
+  {   // the collective self-test the launcher runs before it trusts the transport
+    long long bad = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    CK(mgs_comm_p2p_selftest(c, 240, &bad));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bad != 0) { fprintf(stderr, "rank %d: self-test saw %lld wrong values\n", R, bad); S->bad = 1; _exit(8); }
+    barrier(++gen);
+    if (R == 0) printf("self-test: 240 pattern exchanges with every peer, 0 wrong values, %.1f ms\n", ms);
+  }
   CK(mgs_comm_p2p_info(c, info));
   if (info[4] != 0) { fprintf(stderr, "rank %d: error word %lld\n", R, info[4]); S->bad = 1; _exit(7); }
   barrier(++gen);
-  if (R == 0) {   // stream memory operations on this stack
+  if (R == 0 && !brief) {   // stream memory operations on this stack
     unsigned long long *plain = nullptr, *sig = nullptr;
     HK(hipMalloc((void **)&plain, 64)); HK(hipMemset(plain, 0, 64));
     const hipError_t es = hipExtMallocWithFlags((void **)&sig, 8, hipMallocSignalMemory);

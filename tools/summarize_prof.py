@@ -113,7 +113,11 @@ try:      # the commit whose build was profiled (the summary is written in the b
     dirty = bool(subprocess.run(["git", "-C", REPO, "status", "--porcelain", "--", "multigridsolver_amd", "include", "bench.py", "tools/prof_workload.py"], capture_output=True, text=True).stdout.strip())
 except Exception:  # noqa: BLE001
     code_commit, dirty = None, None
-summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "code_commit": code_commit, "code_dirty": dirty, "vcycle": vcycle, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
+import hashlib
+# identity of the row-block kernels' source: bench.py applies this summary's bytes only to a build of the same text (the file as it is in the
+# working tree NOW — summarise right after the profiled run, before editing kernels)
+ksha = hashlib.sha256(open(os.path.join(REPO, "multigridsolver_amd", "csrc", "kernels_spmv.hip"), "rb").read()).hexdigest()[:16]
+summary = {"tag": tag, "grid": N, "rows": n, "nnz": nnz, "code_commit": code_commit, "code_dirty": dirty, "kernel_source_sha": ksha, "vcycle": vcycle, "tool": "rocprofv3 (ROCm 7.2), tools/run_rocprof.sh, tools/prof_workload.py",
            "fetch_size_correction": cal_read, "write_size_correction": cal_write,
            "note": "FETCH_SIZE on gfx950 reports half the bytes of this access pattern (8-byte lanes): calibrated on axpby's known 16n read bytes; "
                    "counters come from L2's fabric-side requests, so Infinity-Cache hits are included (traffic >= HBM bytes). "
