@@ -424,6 +424,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29755")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from multigridsolver_amd import dist as mgdist
+        args.no_cpu_cross = True        # N > 1: the run's time budget (launch.py) goes to transport generations, not to a second oracle sample
         return mgdist.bench_sharded(args, rank, world, local_rank, log, spmv_bytes, emit_json,
                                     cpu_baseline=None if args.no_cpu else (lambda: cpu_baseline(mg, args)),
                                     pmc_traffic=pmc_traffic)

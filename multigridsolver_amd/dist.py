@@ -554,8 +554,10 @@ class ShardedHierarchy:
         # and installs what it will receive — collective, all levels or none (a rank that cannot keeps every rank on packed sends).
         segs, ok = [], True
         try:
-            if os.environ.get("MGS_NATIVE_SEGMENTS", "1") == "0":
-                raise RuntimeError("MGS_NATIVE_SEGMENTS=0")
+            # default: ranges on the peer-to-peer transport (a range is just another copy of the exchange kernel); packed messages on RCCL, where
+            # ranges mean several ncclSend/ncclRecv per peer inside one group — verified on the stand-in only, never on real RCCL (MGS_NATIVE_SEGMENTS=1 opts in)
+            if os.environ.get("MGS_NATIVE_SEGMENTS", "1" if transport == "p2p" else "0") == "0":
+                raise RuntimeError("packed messages on this transport (MGS_NATIVE_SEGMENTS)")
             for l, plan in enumerate(self.plans):
                 nseg = (C.c_int * comm.world)(); cap = sum(plan.send_counts) + comm.world + 1
                 lens = (C.c_int * cap)()

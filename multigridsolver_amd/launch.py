@@ -35,11 +35,12 @@ EXIT_RETRY = 77
 GENERATIONS = (
     # the library's own peer-to-peer exchange kernels over IPC-mapped device windows (csrc/comm_p2p.hip), cycle captured in a hipGraph;
     # a wait that never ends times out on the device (MGS_P2P_TIMEOUT_S) and the worker exits non-zero: no watchdog period is spent
-    ("native-p2p+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "p2p"}),
-    # RCCL send/recv groups inside the captured cycle, in their most conservative form: one packed message per peer (the pack-free
-    # range sends post several ncclSend/ncclRecv per peer in one group — never run on real RCCL)
-    ("native-rccl+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "rccl", "MGS_NATIVE_SEGMENTS": "0"}),
-    ("native-rccl", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "0", "MGS_NATIVE_TRANSPORT": "rccl", "MGS_NATIVE_SEGMENTS": "0"}),
+    # (a peer-to-peer set-up that fails CLEANLY — window allocation, IPC mapping, self-test, cross-check — is followed by RCCL inside the same generation)
+    ("native-p2p+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "p2p,rccl"}),
+    # RCCL send/recv groups inside the captured cycle, in their most conservative form: one packed message per peer (dist.py's default for
+    # this transport: the pack-free range sends post several ncclSend/ncclRecv per peer in one group — never run on real RCCL)
+    ("native-rccl+graph", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "1", "MGS_NATIVE_TRANSPORT": "rccl"}),
+    ("native-rccl", {"MGS_NATIVE_RCCL": "1", "MGS_NATIVE_GRAPH": "0", "MGS_NATIVE_TRANSPORT": "rccl"}),
     ("torch.distributed-callbacks", {"MGS_NATIVE_RCCL": "0", "MGS_NATIVE_GRAPH": "0"}),
     ("gloo-host-staged", {"MGS_NATIVE_RCCL": "0", "MGS_NATIVE_GRAPH": "0", "MGS_DIST_BACKEND": "gloo"}),
 )
@@ -54,6 +55,8 @@ def first_generation(env=None):
     """the generation a run starts in: an explicit MGS_NATIVE_RCCL=0 / MGS_DIST_BACKEND=gloo skips what it rules out"""
     env = os.environ if env is None else env
     if env.get("MGS_DIST_BACKEND") == "gloo":
+        if env.get("MGS_NATIVE_TRANSPORT", "").startswith("p2p") and env.get("MGS_NATIVE_RCCL") != "0":
+            return 0          # the peer-to-peer transport needs torch.distributed for its setup handshakes only: any backend serves (ranks sharing one GPU: rehearsals)
         return 4 if env.get("MGS_NATIVE_RCCL") != "force" else 2
     if env.get("MGS_NATIVE_RCCL") == "0":
         return 3
@@ -178,9 +181,6 @@ def abandoned_generations():
 def _worker_env(base, gen, rank, local_rank, world, addr, port, rundir):
     env = dict(base)
     env.update(GENERATIONS[gen][1])
-    for k in ("MGS_NATIVE_SEGMENTS",):            # an explicit choice of the caller survives the generation's default
-        if k in base:
-            env[k] = base[k]
     if base.get("MGS_NATIVE_RCCL") == "force" and GENERATIONS[gen][1].get("MGS_NATIVE_RCCL") == "1":
         env["MGS_NATIVE_RCCL"] = "force"          # tests: stand-in RCCL without the nccl backend
     if base.get("MGS_DIST_BACKEND") and "MGS_DIST_BACKEND" not in GENERATIONS[gen][1]:

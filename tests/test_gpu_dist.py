@@ -86,7 +86,7 @@ def test_native_cycle_captured_in_a_graph_multi_rank(world, N, tail, opts, trans
     if transport == "p2p":
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p", MGS_EXPECT_GRAPH="1")
     else:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_FAKE_RCCL_STREAM="1")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_FAKE_RCCL_STREAM="1", MGS_NATIVE_SEGMENTS="1")
     if opts:
         env["MGS_OPTIONS"] = opts
     port = 29950 + (os.getpid() % 1000) + world + (7 if opts else 0) + (3 if tail == 700 else 0) + (40 if transport == "p2p" else 0)
@@ -105,7 +105,7 @@ def test_native_transport_multi_rank_matches_oracle(world, N, tail):
     fake = os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so")
     if not os.path.exists(fake):
         subprocess.run(["make", "-C", os.path.dirname(fake)], check=True, capture_output=True)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGS_NATIVE_RCCL="force", MGS_LIBRCCL=fake, MGS_NATIVE_SEGMENTS="1")
     port = 29650 + (os.getpid() % 1000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "tests", "dist_gpu_worker.py"), str(N), str(tail), "1", "1"]
@@ -124,7 +124,7 @@ def test_sharded_general_operator_matches_oracle(world, native, inputs):
     if native == 3:
         env.update(MGS_NATIVE_RCCL="1", MGS_NATIVE_TRANSPORT="p2p", MGS_EXPECT_GRAPH="1")
     elif native:
-        env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so"))
+        env.update(MGS_NATIVE_RCCL="force", MGS_LIBRCCL=os.path.join(REPO, "tests", "fake_rccl", "libfake_rccl.so"), MGS_NATIVE_SEGMENTS="1")
         if native == 2:
             env["MGS_FAKE_RCCL_STREAM"] = "1"
     port = 29700 + (os.getpid() % 1000) + world + 20 * native

@@ -80,9 +80,9 @@ def test_first_generation_honours_explicit_choices():
     assert launch.first_generation({"MGS_NATIVE_RCCL": "0"}) == 3
     assert launch.first_generation({"MGS_DIST_BACKEND": "gloo"}) == 4
     assert launch.first_generation({"MGS_DIST_BACKEND": "gloo", "MGS_NATIVE_RCCL": "force"}) == 2
-    # the RCCL generations run in their conservative form (one packed message per peer) unless the caller says otherwise
-    assert launch.GENERATIONS[1][1]["MGS_NATIVE_SEGMENTS"] == "0"
-    assert launch._worker_env({"MGS_NATIVE_SEGMENTS": "1"}, 1, 0, 0, 2, "127.0.0.1", 1, "/tmp/x")["MGS_NATIVE_SEGMENTS"] == "1"
+    assert launch.first_generation({"MGS_DIST_BACKEND": "gloo", "MGS_NATIVE_TRANSPORT": "p2p"}) == 0
+    # generation 0 tries the peer-to-peer transport, then RCCL, inside one generation; the RCCL generations restrict themselves to RCCL
+    assert launch.GENERATIONS[0][1]["MGS_NATIVE_TRANSPORT"] == "p2p,rccl" and launch.GENERATIONS[1][1]["MGS_NATIVE_TRANSPORT"] == "rccl"
 
 
 @pytest.mark.parametrize("launcher", ["spawn", "torchrun"])

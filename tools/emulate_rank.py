@@ -11,6 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29931")
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+os.environ.setdefault("MGS_NATIVE_SEGMENTS", "1")     # both transports in their pack-free form (the product's default keeps RCCL on packed messages: never run on real links)
 import torch, torch.distributed as dist
 import multigridsolver_amd as mg
 from multigridsolver_amd import dist as mgd
