@@ -908,8 +908,10 @@ __global__ void restrict_stray_kernel(int ns, const int *__restrict__ stray, con
 
 // the grouped pass itself: body of csr_rowblock_coded_kernel<RESIDUAL> per row block (coded table, uncoded index slice, or the
 // unstaged walk — block-uniform choices), then the in-LDS restriction of the group's aggregates
+// (six waves per SIMD: the halo variants of U = 7 / 8 came out at 82 / 89 registers — one wave less than the 80 of the others — and ran 6 % behind
+// their share on a row shard)
 template <int U, bool HALO>
-__global__ __launch_bounds__(RB) void csr_group_pre_kernel(
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(6))) void csr_group_pre_kernel(
     int n, const int *__restrict__ rowptr, const int *__restrict__ idx, const double *__restrict__ val,
     const unsigned char *__restrict__ pid, const int *__restrict__ tptr, const int *__restrict__ tab,
     const double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t_out, double *__restrict__ r_out,
