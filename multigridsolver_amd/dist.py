@@ -653,7 +653,9 @@ class ShardedHierarchy:
         self.tail_A = ctx.csr(n_t, n_t, Ag.indptr, Ag.indices, Ag.data)
         if all(q[3] is not None for q in parts) and int(np.sum(n0)) < 2 ** 31:
             self.tail_A.set_origin(np.concatenate([q[3] for q in parts]).astype(np.int32))
-        self.tail = core.Hierarchy(self.tail_A, *self.smoother).coarsen(ktg, npass, tou, coarse_rows, 32).finalize()
+        # MGS_TAIL_NPASS: pairwise passes of the replicated tail's own coarsening (default: the hierarchy's; 3 = aggregates of up to 8 → fewer,
+        # launch-bound levels per cycle on every rank)
+        self.tail = core.Hierarchy(self.tail_A, *self.smoother).coarsen(ktg, int(os.environ.get("MGS_TAIL_NPASS", npass)), tou, coarse_rows, 32).finalize()
         if log:
             log(f"replicated tail from level {L}: {n_t} global rows, {self.tail.nlev} levels")
         self.tail_offs, self.tail_nlocs = offs, nlocs
