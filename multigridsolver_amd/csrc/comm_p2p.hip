@@ -90,6 +90,7 @@ __global__ __launch_bounds__(P2P_TB) void p2p_exchange_kernel(const P2PArgs a) {
   __shared__ unsigned long long s_seq[P2P_MAXPEER];
   __shared__ int s_last, s_bad;
   const int tid = threadIdx.x;
+  if (*a.err) return;                            // a wait has timed out before: the transport is dead, every later exchange returns at once (the host reads the word)
   if (tid < a.npeer) s_seq[tid] = *a.seq[tid];
   if (tid == 0) { s_last = 0; s_bad = 0; }
   __syncthreads();
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PRedArgs a) {
   __shared__ unsigned long long s_seq[P2P_MAXPEER];
   __shared__ int s_bad;
   const int tid = threadIdx.x;
+  if (*a.err) return;
   if (tid < a.npeer) s_seq[tid] = *a.seq[tid];
   if (tid == 0) s_bad = 0;
   __syncthreads();

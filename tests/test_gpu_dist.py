@@ -171,3 +171,20 @@ def test_native_transports_same_bits_rank_of_8_at_256():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "emulate_rank.py"), "256", "8", "100000"], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0 and "EMU_OK" in r.stdout and r.stdout.count("captured_cycles") >= 2, r.stdout[-3000:] + r.stderr[-6000:]
     assert "transport=p2p" in r.stdout and "transport=rccl" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["exchange", "timeout"])
+def test_p2p_transport_raw_two_processes(mode, tmp_path):
+    """the peer-to-peer transport by itself through the C-ABI (mgs_comm_p2p_create / _connect / _exchange_raw / _allgather_raw / _allreduce_raw /
+    _selftest / _info), two processes on this GPU, handles through files.  "exchange": data exact over both window slots, odd lengths, rank-ordered
+    all-reduce sum.  "timeout": a peer that connects and stays silent — the wait is bounded (MGS_P2P_TIMEOUT_S), the error word is set, later exchanges
+    return at once: no wave spins forever (what the launcher's non-zero exit and generation change rest on)."""
+    env = dict(os.environ, MGS_P2P_TIMEOUT_S="1" if mode == "timeout" else "20")
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "p2p_raw_worker.py"), str(r), str(tmp_path), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env, cwd=REPO) for r in (0, 1)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[0][-1000:], o[1][-3000:]) for p, o in zip(procs, outs)]
+    if mode == "timeout":
+        assert "P2P_TIMEOUT_OK" in outs[0][0] and "P2P_PEER_SILENT" in outs[1][0]
+    else:
+        assert all("P2P_RAW_OK" in o[0] for o in outs)
