@@ -88,12 +88,12 @@ __device__ __forceinline__ void copy_range(const double *__restrict__ src, doubl
 
 __global__ __launch_bounds__(P2P_TB) void p2p_exchange_kernel(const P2PArgs a) {
   __shared__ unsigned long long s_seq[P2P_MAXPEER];
-  __shared__ int s_last, s_bad;
+  __shared__ int s_last, s_bad, s_dead;
   const int tid = threadIdx.x;
-  if (*a.err) return;                            // a wait has timed out before: the transport is dead, every later exchange returns at once (the host reads the word)
   if (tid < a.npeer) s_seq[tid] = *a.seq[tid];
-  if (tid == 0) { s_last = 0; s_bad = 0; }
+  if (tid == 0) { s_last = 0; s_bad = 0; s_dead = *a.err != 0; }
   __syncthreads();
+  if (s_dead) return;                            // a wait has timed out before: the transport is dead, every later exchange returns at once (workgroup-uniform; the host reads the word)
   // ---- phase 1: my ranges into the peers' windows (+ local copies)
   for (int q = 0; q < a.nseg; ++q) {
     const P2PSeg sg = a.seg[q];
@@ -149,11 +149,12 @@ struct P2PRedArgs {
 __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PRedArgs a) {
   __shared__ unsigned long long s_seq[P2P_MAXPEER];
   __shared__ int s_bad;
+  __shared__ int s_dead;
   const int tid = threadIdx.x;
-  if (*a.err) return;
   if (tid < a.npeer) s_seq[tid] = *a.seq[tid];
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_dead = *a.err != 0; }
   __syncthreads();
+  if (s_dead) return;
   const double mine = tid < a.cnt ? a.buf[tid] : 0.0;
   if (tid < a.cnt) for (int p = 0; p < a.npeer; ++p) a.peer_area[p][(s_seq[p] & 1ull) * a.slot_doubles + tid] = mine;
   if ((a.tune & 3) == 0) __threadfence_system(); else if ((a.tune & 3) == 1) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
