@@ -186,8 +186,11 @@ int mgs_hier_set_smoother(mgs_hier *h, double omega, int nu1, int nu2);
 /* K-cycle (docs/AGMG_For_Convection_Diffusion.pdf §3.1, Fortran `nlvcyc`
  * src/CPU_Matlab/dagtwolev_mex.f90:59-61,72): the coarse problems of levels 1..levels are solved
  * by two GCR steps preconditioned by the cycle below instead of one recursive cycle.  0 = V-cycle
- * (default).  Scalars stay on the device.  On a row-sharded hierarchy the five inner products are summed over the
- * ranks (mgs_ctx_set_native_allreduce, else the mgs_ctx_set_allreduce callback); without either the level runs a V-cycle. */
+ * (default).  Scalars stay on the device; the second direction is orthogonalised explicitly against the first (ρ2 = d2'·v2' on the
+ * orthogonalised pair — the paper's β − γ²/ρ1 without the difference of nearly equal numbers).  Option "kcycle_energy" (mgs_ctx_set_option):
+ * coefficients from c instead of v = A·c (flexible-CG form) — SYMMETRIC POSITIVE DEFINITE operators only; the default is the paper's GCR form.
+ * On a row-sharded hierarchy the inner products are summed over the ranks in three reductions per K step
+ * (mgs_ctx_set_native_allreduce, else the mgs_ctx_set_allreduce callback); without either the level runs a V-cycle. */
 int mgs_hier_set_kcycle(mgs_hier *h, int levels);
 /* K iteration on level 0 itself when the hierarchy is applied from x = 0: for the replicated tail of a row-sharded hierarchy whose
  * K-cycle reaches the last sharded level (that level is the tail's level 0; no rank reduction needed: the tail is replicated). */
@@ -228,7 +231,9 @@ int mgs_bicgstab(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h,
  * not a fixed linear operator (BiCGSTAB may break down with it).  Restarted every `restart`
  * directions; same in/out convention as mgs_bicgstab (status 0 converged / 1 max_iter).  Not in the
  * reference's C++ (its Matlab driver calls pcg/bicgstab, src/CPU_Matlab/solve.m:28-33); provided
- * with the K-cycle.                                                      */
+ * with the K-cycle.  Per iteration beside preconditioner and SpMV: one multi-dot pass (new direction against the
+ * window), one fused update pass, one residual pass; x is updated once per window through the triangular coefficient system.  Status 0 is
+ * reported only with the TRUE residual b − A·x below *tol (recomputed at every restart and before every return).  restart 1..64. */
 int mgs_fgcr(const mgs_csr *A, mgs_vec *x, const mgs_vec *b, mgs_hier *h, int restart,
              int *max_iter, double *tol, int *status);
 
