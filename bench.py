@@ -282,6 +282,18 @@ def _oracle_sample(mg, orc, args, Ns, min_cycles, min_seconds, keep_fine=False):
         xg = h.vcycle(ctx.vec(b)).numpy()
         err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
         out = {"grid": Ns, "rows": n, "levels": h.nlev, "cycles": reps, "ms_per_cycle": t_cycle * 1e3, "gpu_vs_oracle_rel_err": err}
+        if keep_fine and h.nlev >= 6:
+            # the K-cycle the solve leg runs (levels 1-4, energy coefficients) against the oracle's K-cycle AT THIS SIZE, same right-hand side
+            # (round-3 review: the benched size had no oracle comparison); the oracle's row loops on the host cores, its inner products sequential
+            try:
+                ctx.set_option("kcycle_energy", 1); h.set_kcycle(4); ho.set_kcycle_energy(1).set_kcycle(4)
+                orc.set_threads(nthr if t_all is not None else 1)
+                t0 = time.perf_counter(); xko = ho.vcycle(b); t_ko = time.perf_counter() - t0
+                xkg = h.vcycle(ctx.vec(b)).numpy()
+                out["kcycle4_energy"] = {"gpu_vs_oracle_rel_err": float(np.linalg.norm(xkg - xko) / np.linalg.norm(xko)), "oracle_seconds": t_ko,
+                                         "oracle_threads": nthr if t_all is not None else 1}
+            finally:
+                orc.set_threads(1); ctx.set_option("kcycle_energy", 0); h.set_kcycle(0); ho.set_kcycle_energy(0).set_kcycle(0)
         if t_all is not None:
             out["all_cores"] = {"threads": nthr, "ms_per_cycle": t_all * 1e3, "same_bits_as_one_thread": bool(np.array_equal(x_all, x)), "ms_per_cycle_by_threads": tried}
         del h, A, ho
@@ -304,7 +316,8 @@ def cpu_baseline(mg, args):
            "sample": f"oracle V({args.nu1},{args.nu2}) cycle on the {Ns}^3 grid ({n} rows, {full['levels']} levels built on device, downloaded once), "
                      f"{full['cycles']} cycles of {full['ms_per_cycle']:.1f} ms after one warm-up cycle"
                      + ("" if scale == 1.0 else f", scaled by the row ratio x{scale:.0f} to {args.grid}^3"),
-           "sample_ms_per_cycle": full["ms_per_cycle"], "gpu_vs_oracle_rel_err_on_sample": full["gpu_vs_oracle_rel_err"]}
+           "sample_ms_per_cycle": full["ms_per_cycle"], "gpu_vs_oracle_rel_err_on_sample": full["gpu_vs_oracle_rel_err"],
+           "kcycle4_energy_on_sample": full.get("kcycle4_energy")}
     if full.get("all_cores"):
         # the whole CYCLE (not only its SpMV) on every host core this job may use: the box gives a 1-GPU job 16 of the host's hardware threads
         # (os.sched_getaffinity), which is the cap stated here; value stays the 1-thread figure (how the reference ships: no -fopenmp)
