@@ -148,11 +148,12 @@ int main(int argc, char **argv) {
   {   // the collective self-test the launcher runs before it trusts the transport
     long long bad = -1;
     const auto t0 = std::chrono::steady_clock::now();
-    CK(mgs_comm_p2p_selftest(c, 240, &bad));
+    const int rounds = getenv("P2P_PROBE_SELFTEST_ROUNDS") ? atoi(getenv("P2P_PROBE_SELFTEST_ROUNDS")) : 240;
+    CK(mgs_comm_p2p_selftest(c, rounds, &bad));
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (bad != 0) { fprintf(stderr, "rank %d: self-test saw %lld wrong values\n", R, bad); S->bad = 1; _exit(8); }
     barrier(++gen);
-    if (R == 0) printf("self-test: 240 pattern exchanges with every peer, 0 wrong values, %.1f ms\n", ms);
+    if (R == 0) printf("self-test: %d pattern exchanges with every peer, 0 wrong values, %.1f ms\n", rounds, ms);
   }
   CK(mgs_comm_p2p_info(c, info));
   if (info[4] != 0) { fprintf(stderr, "rank %d: error word %lld\n", R, info[4]); S->bad = 1; _exit(7); }
