@@ -691,35 +691,21 @@ def test_properties_full_size_512(ctx, mg):
     assert st == 0 and it <= 80 and A.residual(x, u).nrm2() / u.nrm2() <= 1.5e-10, (st, it, tol)
 
 
-def test_c4_shaped_standin_three_level_vcycle(ctx, mg, orc):
+@pytest.mark.parametrize("family", ["convdiff3d", "csky3d"])
+def test_c4_shaped_standin_three_level_vcycle(ctx, mg, orc, family):
     """BASELINE.json configs[3] (matvf3dSky80 + its P, 512 000 rows, 3-level V-cycle) cannot be tested: the inputs are absent from the
-    reference checkout (.MISSING_LARGE_BLOBS).  This is a labelled STAND-IN of the same shape, not that matrix: a nonsymmetric 7-point
-    convection-diffusion operator on an 80^3 grid (upwind differences, rotating velocity field, coefficient jumps by 1e3 in a "skyscraper"
-    column pattern), hierarchy of exactly 3 levels aggregated on the device; the 3-level cycle against the oracle on the downloaded
-    hierarchy (≤1e-10) and the preconditioned solve to 1e-10."""
+    reference checkout (.MISSING_LARGE_BLOBS).  These are labelled STAND-INS of the same shape, not that matrix (multigridsolver_amd/synthetic.py):
+    nonsymmetric 7-point convection-diffusion operators on an 80^3 grid — `convdiff3d`: upwind differences, rotating velocity field, coefficient
+    jumps by 1e3 in a "skyscraper" column pattern; `csky3d`: the family of the reference's bundled CSky3d30 (constant strong convection, periodic
+    cubes of 1e3..9e3 x diffusion; at N = 30 the bundled file bit for bit, tests/test_synthetic.py) — hierarchy of exactly 3 levels aggregated on the device; the 3-level cycle against a scipy restatement on the
+    downloaded hierarchy (<= 1e-10) and the preconditioned solve to 1e-10."""
     import scipy.sparse as sps
+    from multigridsolver_amd import synthetic
     N = 80; n = N ** 3
-    g = (np.arange(N) + 0.5) / N
-    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
-    kappa = np.where(((np.floor(X * 8) + np.floor(Y * 8)) % 3 == 0) & (Z < 0.6), 1e3, 1.0).ravel()       # skyscrapers
-    vel = [(2 * Y * (1 - X ** 2)).ravel() * 200.0, (-2 * X * (1 - Y ** 2)).ravel() * 200.0, (np.sin(np.pi * Z)).ravel() * 50.0]
-    hgrid = 1.0 / N
-    idx = np.arange(n); coord = [idx // (N * N), (idx // N) % N, idx % N]; stride = [N * N, N, 1]
-    rows, cols, vals = [], [], []
-    diag = np.zeros(n)
-    for d in range(3):
-        for sgn in (-1, 1):
-            inside = (coord[d] + sgn >= 0) & (coord[d] + sgn < N)
-            nb = np.where(inside, idx + sgn * stride[d], idx)
-            kf = 2.0 / (1.0 / kappa + 1.0 / kappa[nb])                          # harmonic mean on the face
-            diff = kf / hgrid ** 2
-            conv = np.maximum(-sgn * vel[d], 0.0) / hgrid                      # upwind: only the inflow neighbour
-            w = diff + conv
-            diag += np.where(inside, w, diff)                                  # Dirichlet: the boundary face keeps its diffusion term
-            rows.append(idx[inside]); cols.append(nb[inside]); vals.append(-w[inside])
-    rows.append(idx); cols.append(idx); vals.append(diag)
-    M = sps.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)); M.sort_indices()
-    assert abs(M - M.T).max() > 1.0                                            # nonsymmetric
+    # csky3d: with the bundled file's row-sum margin (synthetic.py: at N != 30 the printed digits alone leave the reference's pair rule nothing to pair)
+    rp_, ci_, v_ = synthetic.convdiff3d(N) if family == "convdiff3d" else synthetic.csky3d(N, rowsum_floor=synthetic.CSKY_ROWSUM_MARGIN)
+    M = sps.csr_matrix((v_, ci_, rp_), shape=(n, n))
+    assert abs(M - M.T).max() > 1e-5 * abs(M).max()                            # nonsymmetric (the largest entries are the 1e3-fold diffusion jumps)
     A = ctx.csr(n, n, M.indptr, M.indices, M.data)
     h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 100, 3).finalize()    # max_levels = 3
     assert h.nlev == 3
