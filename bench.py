@@ -571,9 +571,23 @@ def main():
         kruns.append({"rhs_seed": seed, "status": stk, "iterations": itk, "reported_tol": tolk, "true_residual": A.residual(xk, bk).nrm2() / bk.nrm2(),
                       "seconds": t_solve_k})
         del bk
+    # the same with the smoother's damping the reference's own two-grid tests also run (omega = 0.8, tests/golden jac2grid_w08): beside the default, never instead
+    h.set_smoother(0.8, args.nu1, args.nu2)
+    h.vcycle(b, xk)
+    kruns08 = []
+    for seed in (0, 1, 2):
+        bk = b if seed == 0 else ctx.vec(n).rand(seed=100 + seed)
+        xk.fill(0.0); ctx.sync()
+        t0 = time.perf_counter()
+        stk, itk, tolk = mg.fgcr(A, xk, bk, h, 10, 300, 1e-10)
+        t_solve_k = time.perf_counter() - t0
+        kruns08.append({"rhs_seed": seed, "status": stk, "iterations": itk, "true_residual": A.residual(xk, bk).nrm2() / bk.nrm2(), "seconds": t_solve_k})
+        del bk
+    h.set_smoother(args.omega, args.nu1, args.nu2)
     h.set_kcycle(0)
     ctx.set_option("kcycle_energy", 0)
     h.vcycle(b, x)
+    log("FGCR(10)+K-cycle(4, energy) with omega 0.8: " + "; ".join(f"seed {r['rhs_seed']}: status {r['status']}, {r['iterations']} iterations, {r['seconds']:.2f}s" for r in kruns08))
     log(f"FGCR(10)+K-cycle(4 levels, energy coefficients, {ms_kcycle:.2f} ms per cycle) to 1e-10: " +
         "; ".join(f"seed {r['rhs_seed']}: status {r['status']}, {r['iterations']} iterations, true residual {r['true_residual']:.2e}, {r['seconds']:.2f}s" for r in kruns))
     del xk
@@ -631,7 +645,10 @@ def main():
                         "fgcr10_kcycle4_energy": {"ms_per_kcycle": ms_kcycle, "runs": kruns,
                                                   "spd_only": True,
                                                   "note": "FGCR(10) + K-cycle on levels 1-4 with energy (flexible-CG) coefficients, option kcycle_energy: SYMMETRIC POSITIVE DEFINITE operators only "
-                                                          "(the nonsymmetric leg below uses the paper's GCR form); derived from the paper, no reference executable (parity unpinned)"}},
+                                                          "(the nonsymmetric leg below uses the paper's GCR form); derived from the paper, no reference executable (parity unpinned)"},
+                        "fgcr10_kcycle4_energy_omega08": {"runs": kruns08, "spd_only": True,
+                                                          "note": "the same solve with the smoother's damping omega = 0.8 (a value the reference's own two-grid tests run; the headline "
+                                                                  "cycle and every figure above use the default 0.6); tools/fgcr_knobs.py scans omega x K levels x restart length"}},
     }
     del h, A, b, x, xsol, dinv
     ctx.close()
