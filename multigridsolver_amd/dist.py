@@ -521,11 +521,13 @@ class ShardedHierarchy:
                 ok = False; err = e
             if not agree(ok):
                 return fail("mapping the peers' windows", locals().get("err"))
-            # collective self-test before anything relies on the windows: 240 pattern exchanges with every peer, verified on the device
-            # (sizes 512 KiB ... 8 B, both window slots reused throughout) — this is the first time the transport sees THIS machine's links
+            # collective self-test before anything relies on the windows: 2400 pattern exchanges with every peer, verified on the device
+            # (sizes 512 KiB ... 8 B, both window slots reused throughout; ~40 ms) — this is the first time the transport sees THIS machine's
+            # links, and the ordering it ships (stores acknowledged, no cache maintenance: comm_p2p.hip) has only ever been verified between
+            # processes on ONE GPU: a flag that overtakes its data on real links shows up here, on the large messages, and ends the generation
             try:
                 bad = C.c_longlong(-1)
-                check(lib().mgs_comm_p2p_selftest(c, int(os.environ.get("MGS_P2P_SELFTEST_ROUNDS", "240")), C.byref(bad)), ctx.h)
+                check(lib().mgs_comm_p2p_selftest(c, int(os.environ.get("MGS_P2P_SELFTEST_ROUNDS", "2400")), C.byref(bad)), ctx.h)
                 ok = bad.value == 0
                 if not ok:
                     err = RuntimeError(f"{bad.value} wrong values received")
