@@ -112,7 +112,7 @@ def csky3d(N, velocity=1000.0, workers=None, digits=6, rowsum_floor=None):
         + stride -D_face*h; the diagonal always carries six diffusion and three convection terms (Dirichlet data on all six faces).
       * digits = 6 (default): every value is rounded to six significant decimal digits, as `writeMatrix` prints them (src/common/MatrixIO.cpp:39-57,
         default stream precision) — with it csky3d(30) IS the bundled matrix, bit for bit after parsing.  This is not cosmetic: interior rows
-        have zero row sums, the reference's pair test `a_ii - s_i + a_jj - s_j >= 0` (Aggregation.cu:157-159) then hangs on the sign of
+        have zero row sums, the reference's pair test `a_ii - s_i + a_jj - s_j >= 0` (src/CPU_C++/AGMG.cpp:159,233; src/GPU_CUDAC++/Aggregation.cu:157) then hangs on the sign of
         rounding noise, and its setup coarsens the exact operator 1.4x per level instead of the 3.7x it reaches on its own files, whose printed
         digits leave most row sums at +2.86e-6 * a_ii (oracle AGMG on N = 30: 27000 -> 18651 exact, -> 7283 printed).  digits = None: exact values;
       * rowsum_floor (default None: values exactly as printed): at other N the printed digits fall differently (N = 64: every background row sum
