@@ -860,7 +860,8 @@ def _oracle_hierarchy(h, orc, A0=None, omega=0.6):
 def test_kcycle_vs_oracle_at_128(ctx, mg, orc):
     """The K-cycle against the oracle at 128^3 (2.1 M rows, the size the round-3 multi-rank run went red at), ONE bar for every size: 1e-9.
     * energy form (the form for SPD operators, used on this Poisson operator by bench.py) on K = 1 and K = 4 levels;
-    * GCR form (the paper's, for nonsymmetric operators) on the nonsymmetric convection-diffusion stand-in at 64^3.
+    * GCR form (the paper's, for nonsymmetric operators) on the nonsymmetric convection-diffusion stand-ins at 64^3 (`convdiff3d`, and `csky3d` — the
+      family of the reference's bundled CSky3d30, the operator of bench.py's convection-diffusion leg), K on one level and on all.
     The second Krylov direction is orthogonalised explicitly (no rho2 = beta - gamma^2/rho1), on the device and in the oracle.
     The GCR form on the POISSON operator is a badly conditioned map whatever the arithmetic — its first step is tiny (alpha1/rho1 = 0.02), so
     c2 = B(r - 0.02 v1) is almost c1 and x = k1 c1 + k2 c2 has k1 = -32.6, k2 = 33.3: a 1e-16 relative perturbation of the INPUT moves the oracle's
@@ -898,9 +899,14 @@ def test_kcycle_vs_oracle_at_128(ctx, mg, orc):
     # downloaded hierarchy.
     import scipy.sparse as sps
     import scipy.sparse.linalg as spla
-    from multigridsolver_amd.synthetic import convdiff3d
+    from multigridsolver_amd import synthetic
     Nc = 64; nc = Nc ** 3
-    rp, ci, v = convdiff3d(Nc)
+    # ... and on the family of the reference's bundled CSky3d30 (bench.py's convection-diffusion leg: K on every level below the finest)
+    for family, (rp, ci, v) in (("convdiff3d", synthetic.convdiff3d(Nc)), ("csky3d", synthetic.csky3d(Nc, rowsum_floor=synthetic.CSKY_ROWSUM_MARGIN))):
+        _kcycle_gcr_against_scipy(ctx, mg, family, nc, rp, ci, v, sps, spla)
+
+
+def _kcycle_gcr_against_scipy(ctx, mg, family, nc, rp, ci, v, sps, spla):
     Ac = ctx.csr(nc, nc, rp, ci, v)
     hc = mg.Hierarchy(Ac, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 6).finalize()
     assert hc.nlev >= 3
@@ -943,11 +949,11 @@ def test_kcycle_vs_oracle_at_128(ctx, mg, orc):
         return k1 * c1 + k2 * c2
 
     bc = ctx.vec(nc).rand(seed=8); bc_np = bc.numpy()
-    assert rel(hc.vcycle(bc).numpy(), cyc(0, bc_np, 0)) <= 1e-10
+    assert rel(hc.vcycle(bc).numpy(), cyc(0, bc_np, 0)) <= 1e-10, family
     for kl in sorted({1, hc.nlev - 2}):
         hc.set_kcycle(kl)
         e = rel(hc.vcycle(bc).numpy(), cyc(0, bc_np, kl))
-        assert e <= 1e-9, ("GCR form, convection-diffusion", kl, e)
+        assert e <= 1e-9, ("GCR form", family, kl, e)
     hc.set_kcycle(0)
 
 
