@@ -1433,3 +1433,41 @@ print("ARENA", cap, x1.tobytes().hex()[:64], np.float64(s1).sum().hex(), it1)
         outs[gb] = r.stdout.strip().split("\n")[-1].split()
     assert outs["0"][1] == "0" and int(outs["0.0625"][1]) == 64 << 20, outs
     assert outs["0"][2:] == outs["0.0625"][2:], "results differ with the arena"
+
+
+def test_bench_line_contract_small_grid():
+    """bench.py as the driver runs it (one process, one GPU), at a small grid so that the whole run takes seconds: ONE JSON line on stdout with the
+    contract's fields, `roofline` and `cpu_baseline` objects, and the solve checks — every solve converged on its TRUE residual, the convection-
+    diffusion leg included.  (The oracle is used by the cpu_baseline leg only.)"""
+    import json, subprocess, sys
+    from conftest import REPO
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--grid", "96", "--steps", "5", "--warmup", "2", "--kernel-reps", "5",
+                        "--convdiff-grid", "48", "--no-cpu-cross"], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "solve_check"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["unit"] == "V-cycles/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
+    s = d["solve_check"]
+    assert s["bicgstab_status"] == 0
+    for leg in ("fgcr10_kcycle4_energy", "fgcr10_kcycle4_energy_omega08"):
+        assert all(run["status"] == 0 and run["true_residual"] <= 1.5e-10 for run in s[leg]["runs"]), s[leg]
+    assert s["fgcr10_kcycle4_energy"]["spd_only"] is True
+    cd = s["convdiff_48"]
+    assert "error" not in cd and len(cd["runs"]) == 3
+    for run in cd["runs"]:
+        assert run["bicgstab_vcycle"]["status"] == 0 and run["bicgstab_vcycle"]["true_residual"] <= 2e-10
+        assert run["fgcr10_kcycle_gcr"]["true_residual"] <= 2e-10 or run["fgcr10_kcycle_gcr"]["status"] != 0      # status 0 only on the true residual
