@@ -230,9 +230,9 @@ def convdiff_leg(mg, args, N=256):
                "note": "K-cycle in the paper's GCR form (nonsymmetric operator: the energy form of the Poisson leg is for SPD operators only) on every level below the "
                        "finest: the hierarchy coarsens 4x per level, so the K-cycle costs about what a W-cycle costs.  Iterations to 1e-10 at 128^3 / 256^3 / 512^3: BiCGSTAB + V "
                        "61 / 107-117 / 208-212; FGCR(10) + K 36 / 43 / no convergence in 300 (restarted GCR stagnates at 0.77); BiCGSTAB + K (a nonlinear preconditioner "
-                       "inside BiCGSTAB: outside the theory) 21 / 31-45 / 65-69 with one of three right-hand sides not converging.  In seconds BiCGSTAB + V wins at every "
-                       "size (256^3: 0.30 s against 0.39 s; 512^3: 3.8 s against 4.4 s): with the reference's Jacobi smoother and plain pairwise aggregates the K-cycle "
-                       "lowers the iteration count but is not mesh-independent on this class.  K on the top 1-2 levels only does not converge inside FGCR(10) at 256^3 "
+                       "inside BiCGSTAB: outside the theory) 21 / 31-45 / 65-69 with one of three right-hand sides not converging.  In seconds the two are level at 256^3 "
+                       "(BiCGSTAB + V 0.29-0.36 s, FGCR(10) + K 0.31 s since the K-cycle's coarse levels replay from one graph) and BiCGSTAB + V wins at 512^3 (3.8 s against 4.4 s): "
+                       "with the reference's Jacobi smoother and plain pairwise aggregates the K-cycle lowers the iteration count but is not mesh-independent on this class.  K on the top 1-2 levels only does not converge inside FGCR(10) at 256^3 "
                        "(tools/convdiff_scan.py; profiles/r04_csky_scan.md).  Cycle-vs-oracle parity on nonsymmetric operators: "
                        "tests/test_gpu_parity.py::test_kcycle_vs_oracle_at_128 and ::test_c4_shaped_standin_three_level_vcycle, bundled CSky operators in "
                        "::test_bundled_operators_vs_reference_golden"}

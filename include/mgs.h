@@ -390,7 +390,10 @@ int mgs_hier_group_info(const mgs_hier *h, int level, int64_t out[4]);
 /* hipGraph state of the cycle (diagnostics): out[0] captured cycles cached, out[1] = 1 on the native RCCL transport, out[2] = 1 if
  * capturing the native cycle failed (eager launches since), out[3] eager native cycles run before the first capture.
  * Option "native_graph" (default 1): capture the row-sharded cycle including its RCCL exchanges (two eager cycles first).
- * Option "native_overlap" (default 0): inside that graph, interior row blocks of the big levels on a second stream beside the exchange. */
+ * Option "native_overlap" (default 0): inside that graph, interior row blocks of the big levels on a second stream beside the exchange.
+ * Option "graph_split_rows" (default 1048576; 0 = never): with a K-cycle on an unsharded operator of at least this many rows the fine level's two passes are launched
+ * eagerly and the levels below replay from ONE graph that does not depend on (b, x): hipGraphLaunch of a K-cycle's hundreds of nodes takes ≈1.1 ms before its first
+ * kernel starts, which then hides behind the fine level's pre pass, and a flexible Krylov method's ten direction vectors no longer overrun the (b, x) cache.  Same kernels, same bits. */
 int mgs_hier_graph_info(const mgs_hier *h, int64_t out[4]);
 
 /* kernel-variant knobs for A/B measurements (initial values of every context: environment MGS_OPTIONS="key=value,...").  key: "spmv_variant", "xcd_remap", "nontemporal",

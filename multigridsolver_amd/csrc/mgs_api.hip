@@ -240,6 +240,7 @@ int mgs_ctx_set_option(mgs_ctx *ctx, const char *key, int value) {
   else if (k == "nontemporal") ctx->opt_nontemporal = value;
   else if (k == "spmv_variant") ctx->opt_spmv_variant = value;
   else if (k == "graph") ctx->opt_graph = value;
+  else if (k == "graph_split_rows") ctx->opt_graph_split_rows = value;
   else if (k == "strip") ctx->opt_strip = value;
   else if (k == "fuse") ctx->opt_fuse = value;
   else if (k == "lds_pad") ctx->opt_lds_pad = value;
@@ -543,6 +544,7 @@ static void level_free(mgs_level &L) {
 }
 static void drop_graph(mgs_hier *h) {
   for (auto &g : h->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); g = mgs_hier::GraphSlot(); }
+  if (h->coarse_exec) { hipGraphExecDestroy(h->coarse_exec); h->coarse_exec = nullptr; }
 }
 
 extern "C" {
@@ -978,6 +980,10 @@ static int coarse_solve_inner(mgs_hier *h, int l, const double *rhs, double *x);
 // e_c for the level above; with an over-correction factor σ ≠ 1 (mgs_hier_set_correction_scale) it is scaled here, once, on the
 // coarse vector (n_c entries), so every form of the level above — fused, grouped, unfused, K-cycle — sees σ·e_c
 static int coarse_solve(mgs_hier *h, int l, const double *rhs, double *x) {
+  if (l == 1 && h->coarse_launch && h->coarse_exec && rhs == h->lev[1].b->d && x == h->lev[1].x->d) {     // split launch (mgs_vcycle): everything below the fine level, one replay
+    MGS_HIP(h->ctx, hipGraphLaunch(h->coarse_exec, h->ctx->stream));
+    return MGS_OK;
+  }
   MGS_TRY(coarse_solve_inner(h, l, rhs, x));
   if (h->corr_scale != 1.0) {
     // (the last sharded level's halo slots were filled from the replicated tail's solution together with the owned entries: scale them as well)
@@ -1315,7 +1321,29 @@ int mgs_vcycle(mgs_hier *h, const mgs_vec *b, mgs_vec *x, int zero_guess) {
   const bool use_graph = ctx->opt_graph && (native ? native_ok : (!h->halo && !h->halo_begin && !h->coarse));
   if (h->graph_epoch != ctx->opt_epoch) drop_graph(h);
   h->graph_epoch = ctx->opt_epoch;
-  if (!use_graph) {
+  // Split launch: a K-cycle's graph has hundreds of nodes (1.1 ms from hipGraphLaunch to its first kernel at 512³, and a cache keyed by
+  // (b, x) that a flexible Krylov method with ten direction vectors overruns).  The fine level's passes go out eagerly instead, and the
+  // levels below — which only touch their own buffers — replay from ONE graph whose submission hides behind the fine level's pre pass.
+  const bool split_launch = use_graph && !native && zero_guess && h->kcycle_levels > 0 && !h->kcycle_entry && !h->additive && h->lev.size() > 2 &&
+                            ctx->opt_graph_split_rows > 0 && L0.n >= ctx->opt_graph_split_rows && h->lev[1].b && h->lev[1].x;
+  if (split_launch) {
+    if (!h->coarse_exec) {
+      hipGraph_t g = nullptr;
+      MGS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      h->capturing = true;
+      int rc = coarse_solve(h, 1, h->lev[1].b->d, h->lev[1].x->d);
+      h->capturing = false;
+      hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+      if (e == hipSuccess && rc == MGS_OK) { e = hipGraphInstantiate(&h->coarse_exec, g, nullptr, nullptr, 0); if (e != hipSuccess) h->coarse_exec = nullptr; }
+      if (g) hipGraphDestroy(g);
+      if (rc != MGS_OK) return rc;
+      if (e != hipSuccess) return mgs_fail(ctx, MGS_ERR_HIP, "coarse-level capture: %s", hipGetErrorString(e));
+    }
+    h->coarse_launch = true;
+    int rc = cycle_level(h, 0, b->d, xw, true);
+    h->coarse_launch = false;
+    MGS_TRY(rc);
+  } else if (!use_graph) {
     MGS_TRY(entry(b->d, xw, zero_guess != 0));
   } else {
     const int zg = zero_guess != 0;

@@ -34,6 +34,8 @@ struct mgs_ctx {
   int opt_fuse_operands = 1; // precomputed operands Â = A·diag(wd), agg[col] for the fused passes (+12 B per entry of memory)
   int opt_spmv_variant = 0;  // 0 auto (stream), 1 force vector
   int opt_graph = 1;
+  int opt_graph_split_rows = 1 << 20;   // K-cycle on an unsharded operator with at least this many rows: the fine level's two passes are launched eagerly and only the
+                                        // levels below replay from ONE hipGraph that does not depend on (b, x) — its submission hides behind the fine level's pre pass (0: never)
   int opt_valcode = 0;   // pattern tuples include the VALUES (rows with equal index shape and equal values share a tuple): coded blocks stream no
                          // matrix entry at all.  Pays only where coefficients repeat (constant-coefficient / piecewise-constant operators): opt-in.
   int opt_nt_store = 1000000;  // streaming (`nt`) stores of the row-block kernels' outputs on operators with at least this many rows (0: never): SpMV −3.4 %, cycle −1.3 % at 512³
@@ -266,6 +268,8 @@ struct mgs_hier {
   int native_eager_runs = 0;
   bool native_graph_failed = false;
   bool capturing = false;
+  hipGraphExec_t coarse_exec = nullptr;  // split launch (opt_graph_split_rows): coarse_solve(level 1) on the level's own buffers, captured once
+  bool coarse_launch = false;            // set around the eager fine-level passes: coarse_solve(h, 1, ..) replays coarse_exec
   std::vector<hipEvent_t> fork_events;   // fork/join events of the captured native cycle (two per overlapped exchange)
   size_t fork_used = 0;
 };

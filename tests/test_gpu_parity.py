@@ -1471,3 +1471,35 @@ def test_bench_line_contract_small_grid():
     for run in cd["runs"]:
         assert run["bicgstab_vcycle"]["status"] == 0 and run["bicgstab_vcycle"]["true_residual"] <= 2e-10
         assert run["fgcr10_kcycle_gcr"]["true_residual"] <= 2e-10 or run["fgcr10_kcycle_gcr"]["status"] != 0      # status 0 only on the true residual
+
+
+def test_kcycle_split_launch_same_bits(ctx, mg):
+    """option graph_split_rows (default 2^20 rows): a K-cycle on a large unsharded operator launches the fine level's two passes eagerly and replays
+    everything below from ONE graph that does not depend on (b, x).  Same kernels in the same order: the cycle and an FGCR solve around it must give
+    the BITS of the one-graph-per-(b, x) form and of plain eager launches."""
+    N = 128; n = N ** 3
+    A = ctx.poisson3d(N)
+    h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
+    b = ctx.vec(n).rand(seed=21)
+    out = {}
+    try:
+        ctx.set_option("kcycle_energy", 1)
+        for name, opts in (("split", {"graph": 1, "graph_split_rows": 1 << 20}), ("whole", {"graph": 1, "graph_split_rows": 0}), ("eager", {"graph": 0, "graph_split_rows": 0})):
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            h.set_kcycle(3)
+            xs = [h.vcycle(b).numpy() for _ in range(3)]                      # first call captures, the next replay
+            assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
+            x = ctx.vec(n)
+            st, it, tol = mg.fgcr(A, x, b, h, 10, 100, 1e-10)
+            assert st == 0
+            out[name] = (xs[0], x.numpy(), it)
+            if name == "split":
+                h.set_kcycle(0); v0 = h.vcycle(b).numpy(); h.set_kcycle(3)   # the plain cycle in between drops nothing it should keep
+                assert np.array_equal(h.vcycle(b).numpy(), xs[0])
+        for name in ("whole", "eager"):
+            assert np.array_equal(out["split"][0], out[name][0]), name
+            assert np.array_equal(out["split"][1], out[name][1]) and out["split"][2] == out[name][2], name
+        assert v0 is not None
+    finally:
+        ctx.set_option("graph", 1); ctx.set_option("graph_split_rows", 1 << 20); ctx.set_option("kcycle_energy", 0)

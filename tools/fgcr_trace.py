@@ -26,12 +26,20 @@ if len(sys.argv) > 2 and sys.argv[1] == "summarize":
         e = by.setdefault(key, [0, 0]); e[0] += 1; e[1] += d
         if nm.startswith("csr_rowblock_coded_kernel<0") and big: spmv_fine += 1
     its = max(spmv_fine - 1, 1)
+    gaps = [int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) for i in range(s + 1, len(rows))]
+    big = sorted(((g, i) for i, g in enumerate(gaps, start=s + 1) if g > 20000), reverse=True)
+    print(f"gaps between consecutive kernels: total {sum(g for g in gaps if g > 0) / 1e6:.2f} ms; {len(big)} gaps above 20 us sum {sum(g for g, _ in big) / 1e6:.2f} ms; largest: "
+          + ", ".join(f"{g / 1e3:.0f} us before `{names[i][:40]}`" for g, i in big[:8]) + "\n")
     print(f"traced solve: {(t1 - t0) / 1e6:.1f} ms wall, {sum(v[1] for v in by.values()) / 1e6:.1f} ms in kernels, fine-level SpMV launches {spmv_fine} (iterations ~ {its})\n")
     print("| kernel | level | launches | total ms | ms per iteration |\n|---|---|---|---|---|")
     for (nm, lv), (c, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:28]:
         print(f"| `{nm}` | {lv} | {c} | {d / 1e6:.2f} | {d / 1e6 / its:.3f} |")
     sys.exit(0)
 os.environ.setdefault("MGS_ARENA_GB", "110")
+GRAPH = os.environ.get("FGCR_TRACE_GRAPH", "0") == "1"      # replayed cycles as in the product: needs torch loaded first (see below)
+if GRAPH:
+    import torch
+    torch.cuda.init()
 import multigridsolver_amd as mg
 N = 512; n = N ** 3
 ctx = mg.Context(0)
@@ -39,7 +47,8 @@ A = ctx.poisson3d(N)
 h = mg.Hierarchy(A, 0.6, 1, 1).coarsen(10.0, 2, 8.0, 2500, 32).finalize()
 b = ctx.vec(n).rand(seed=0); x = ctx.vec(n)
 A.optimize()
-ctx.set_option("graph", 0)                    # eager launches: every kernel its own dispatch (and rocprofv3 7.2 crashes in the capture of this solve when torch is not loaded first)
+if not GRAPH:
+    ctx.set_option("graph", 0)                # eager launches: every kernel its own dispatch (and rocprofv3 7.2 crashes in the capture of this solve when torch is not loaded first)
 for _ in range(2): h.vcycle(b, x)
 ctx.set_option("kcycle_energy", 1); h.set_kcycle(4)
 for _ in range(2): h.vcycle(b, x)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of one FGCR(10) + K(4, energy) solve at 512^3 → gpurun_out/trace_fgcr/summary.md
+# kernel trace of one FGCR(10) + K(4, energy) solve at 512^3 → gpurun_out/trace_fgcr/summary.md   (FGCR_TRACE_GRAPH=1: cycles replayed from their hipGraph, as in the product)
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/trace_fgcr
