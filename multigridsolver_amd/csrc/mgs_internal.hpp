@@ -257,9 +257,9 @@ struct mgs_hier {
   mgs_coarse_fn coarse = nullptr;   // replaces the dense coarsest solve (replicated tail of a sharded hierarchy)
   void *coarse_user = nullptr;
   // hipGraph cache of one V-cycle
-  // small cache of captured cycles keyed by (b, x, zero_guess): BiCGSTAB alternates two (rhs, out) pairs
+  // small cache of captured cycles keyed by (b, x, zero_guess)
   struct GraphSlot { hipGraphExec_t exec = nullptr; const double *b = nullptr; double *x = nullptr; int zero = -1; unsigned long long stamp = 0; };
-  static constexpr int kGraphSlots = 4;
+  static constexpr int kGraphSlots = 16;   // BiCGSTAB alternates two (rhs, out) pairs; flexible GCR(m) cycles through m directions (restart 10: ten pairs)
   GraphSlot graphs[kGraphSlots];
   unsigned long long graph_clock = 0;
   unsigned long long graph_epoch = 0;   // ctx->opt_epoch the cached graphs were captured under
