@@ -188,3 +188,31 @@ def test_p2p_transport_raw_two_processes(mode, tmp_path):
         assert "P2P_TIMEOUT_OK" in outs[0][0] and "P2P_PEER_SILENT" in outs[1][0]
     else:
         assert all("P2P_RAW_OK" in o[0] for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_line_under_the_drivers_launcher(world):
+    """the driver's own N > 1 command — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N --steps K --warmup W` — with the ranks sharing this one GPU (gloo rendezvous: RCCL refuses two ranks per device; the peer-to-peer transport
+    is the real one, IPC windows between the processes): supervisors, workers, first generation, ONE JSON line from rank 0 with the contract's fields,
+    not degraded, on the peer-to-peer transport with its cycle captured, its solve converged."""
+    import json
+    env = dict(os.environ, MGS_DIST_BACKEND="gloo", MGS_DIST_SHARE_GPU="1", MGS_ARENA_GB="0", MGS_NATIVE_TRANSPORT="p2p")   # launch.first_generation: gloo + p2p starts in generation 0
+    for k in ("MGS_NATIVE_RCCL", "MGS_OPTIONS", "MGS_BENCH_WORKER"):
+        env.pop(k, None)
+    port = 29400 + (os.getpid() % 500) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--grid", "128", "--no-cpu", "--kernel-reps", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == world and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "V-cycles/s"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["degraded"] is False and d["abandoned_generations"] == [], d.get("abandoned_generations")
+    t = d["transport"]
+    assert t["native"] == "p2p" and t["world"] == world and t["p2p"] is not None, t
+    assert "multi_gpu_note" in d
