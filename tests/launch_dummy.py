@@ -19,6 +19,9 @@ def main():
             sys.exit(launch.supervise_rank(sys.argv))
         sys.exit(launch.spawn_ranks(sys.argv, int(sys.argv[3])))
     gen, rank = int(os.environ["MGS_BENCH_GEN"]), int(os.environ["RANK"])
+    if gen >= ok_from:
+        import torch                       # before the watchdog starts, as in bench.py: the first import on a cold machine can take longer than the tests' 4 s period
+        import torch.distributed as dist
     wd = launch.Watchdog()
     if gen < ok_from:
         if mode == "hang":
@@ -26,8 +29,6 @@ def main():
                 time.sleep(3600)          # the watchdog must end this
             sys.exit(launch.EXIT_RETRY)
         sys.exit(3 if rank == 0 else launch.EXIT_RETRY)
-    import torch
-    import torch.distributed as dist
     wd.beat("init")
     launch.init_process_group("gloo")
     t = torch.tensor([float(dist.get_rank())])
