@@ -50,11 +50,14 @@ A.optimize()
 if not GRAPH:
     ctx.set_option("graph", 0)                # eager launches: every kernel its own dispatch (and rocprofv3 7.2 crashes in the capture of this solve when torch is not loaded first)
 for _ in range(2): h.vcycle(b, x)
-ctx.set_option("kcycle_energy", 1); h.set_kcycle(4)
-for _ in range(2): h.vcycle(b, x)
-mg.fgcr(A, x, b, h, 10, 300, 1e-10)            # warm (operands, graph capture)
+SOLVER = os.environ.get("FGCR_TRACE_SOLVER", "fgcr")   # "bicgstab": BiCGSTAB + plain V-cycle instead
+if SOLVER == "fgcr":
+    ctx.set_option("kcycle_energy", 1); h.set_kcycle(4)
+    for _ in range(2): h.vcycle(b, x)
+solve = (lambda: mg.fgcr(A, x, b, h, 10, 300, 1e-10)) if SOLVER == "fgcr" else (lambda: mg.bicgstab(A, x, b, h, 300, 1e-10))
+x.fill(0.0); solve()                           # warm (operands, graph capture)
 b.rand(seed=0); x.fill(0.0); b.rand(seed=0)    # marker: rand_kernel launches
-st, it, tol = mg.fgcr(A, x, b, h, 10, 300, 1e-10)
+st, it, tol = solve()
 ctx.sync()
 print("status", st, "iterations", it, "tol", tol, flush=True)
 ctx.close()
